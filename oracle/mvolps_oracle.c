@@ -1,0 +1,955 @@
+/*
+ * mvolps_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See the header.
+ *
+ * LP core: dense condensed-tableau bounded-variable simplex standing in for
+ * glp_simplex (/root/reference/bs.cpp:117,279,287).  GLPK itself is not in the image;
+ * results are pinned against scipy/HiGHS fixtures (tests/golden).  "parity unpinned"
+ * with respect to GLPK's own pivot sequence.
+ *
+ * Determinism contract (mirrored by the HIP engine, bit for bit):
+ *   - every product-sum that feeds the tableau uses fma() exactly where written here,
+ *     and nowhere else (build with -ffp-contract=off);
+ *   - every arg-min / arg-max has a total order (value, then magnitude, then index).
+ */
+#include "mvolps_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define INF HUGE_VAL
+#define ROWCOMB_CHUNK 64
+
+struct orc_prob {
+  int m, n, m_cap, n_cap;
+  int dir;
+  double **A;    /* A[i] (i=1..m) -> n_cap+1 doubles, 1-based columns */
+  double *c;     /* c[0..n] */
+  int *kind;     /* kind[1..n] */
+  char **cname;  /* cname[1..n] or NULL */
+  int *rtype;
+  double *rlb, *rub; /* normalised: -INF / +INF when absent */
+  int *ctype;
+  double *clb, *cub;
+  /* engine state */
+  int valid;
+  int ld;
+  double *T;     /* (m_cap+1) x ld */
+  int *bvar;     /* bvar[1..m] */
+  double *blb, *bub;
+  int *nvar;     /* nvar[1..n] */
+  int *nflag;    /* ORC_NL / NU / NF / NS */
+  double *nlb, *nub;
+  int status;
+  int it_cnt;
+};
+
+static int g_term_out = 1;
+
+/* ------------------------------------------------------------------ helpers */
+static void *xcalloc(size_t n, size_t sz) {
+  void *p = calloc(n ? n : 1, sz);
+  if (!p) {
+    fprintf(stderr, "orc: out of memory\n");
+    abort();
+  }
+  return p;
+}
+static void *xrealloc(void *p, size_t sz) {
+  p = realloc(p, sz ? sz : 1);
+  if (!p) {
+    fprintf(stderr, "orc: out of memory\n");
+    abort();
+  }
+  return p;
+}
+static void fault(const char *msg) {
+  /* GLPK aborts on invalid arguments [GLPK-recalled]; so does the oracle. */
+  fprintf(stderr, "orc: %s\n", msg);
+  abort();
+}
+
+static void norm_bounds(int type, double lb, double ub, double *olb, double *oub) {
+  switch (type) {
+    case ORC_FR: *olb = -INF; *oub = INF; break;
+    case ORC_LO: *olb = lb; *oub = INF; break;
+    case ORC_UP: *olb = -INF; *oub = ub; break;
+    case ORC_DB: *olb = lb; *oub = ub; break;
+    case ORC_FX: *olb = lb; *oub = lb; break;
+    default: fault("invalid bound type");
+  }
+}
+
+static int std_flag(int type) {
+  /* glp_std_basis convention [GLPK-recalled]: NL if a lower bound exists, else NU,
+     free -> NF, fixed -> NS */
+  switch (type) {
+    case ORC_FR: return ORC_NF;
+    case ORC_LO: return ORC_NL;
+    case ORC_UP: return ORC_NU;
+    case ORC_DB: return ORC_NL;
+    default: return ORC_NS;
+  }
+}
+
+static double nb_value(int flag, double lb, double ub) {
+  switch (flag) {
+    case ORC_NL: return lb;
+    case ORC_NU: return ub;
+    case ORC_NS: return lb;
+    default: return 0.0;
+  }
+}
+
+/* ---------------------------------------------------------------- lifecycle */
+orc_prob *orc_create_prob(void) {
+  orc_prob *P = (orc_prob *)xcalloc(1, sizeof(orc_prob));
+  P->dir = ORC_MIN; /* GLPK default [GLPK-recalled] */
+  P->c = (double *)xcalloc(1, sizeof(double));
+  P->status = ORC_UNDEF;
+  return P;
+}
+
+static void free_contents(orc_prob *P) {
+  for (int i = 1; i <= P->m; i++) free(P->A[i]);
+  free(P->A);
+  free(P->c);
+  free(P->kind);
+  if (P->cname) {
+    for (int j = 1; j <= P->n; j++) free(P->cname[j]);
+    free(P->cname);
+  }
+  free(P->rtype); free(P->rlb); free(P->rub);
+  free(P->ctype); free(P->clb); free(P->cub);
+  free(P->T);
+  free(P->bvar); free(P->blb); free(P->bub);
+  free(P->nvar); free(P->nflag); free(P->nlb); free(P->nub);
+}
+
+void orc_erase_prob(orc_prob *P) {
+  free_contents(P);
+  memset(P, 0, sizeof(*P));
+  P->dir = ORC_MIN;
+  P->c = (double *)xcalloc(1, sizeof(double));
+  P->status = ORC_UNDEF;
+}
+
+void orc_delete_prob(orc_prob *P) {
+  if (!P) return;
+  free_contents(P);
+  free(P);
+}
+
+static void ensure_rows(orc_prob *P, int m_new) {
+  if (m_new <= P->m_cap) return;
+  int cap = P->m_cap ? P->m_cap : 8;
+  while (cap < m_new) cap *= 2;
+  P->A = (double **)xrealloc(P->A, (size_t)(cap + 1) * sizeof(double *));
+  P->rtype = (int *)xrealloc(P->rtype, (size_t)(cap + 1) * sizeof(int));
+  P->rlb = (double *)xrealloc(P->rlb, (size_t)(cap + 1) * sizeof(double));
+  P->rub = (double *)xrealloc(P->rub, (size_t)(cap + 1) * sizeof(double));
+  P->bvar = (int *)xrealloc(P->bvar, (size_t)(cap + 1) * sizeof(int));
+  P->blb = (double *)xrealloc(P->blb, (size_t)(cap + 1) * sizeof(double));
+  P->bub = (double *)xrealloc(P->bub, (size_t)(cap + 1) * sizeof(double));
+  if (P->T) P->T = (double *)xrealloc(P->T, (size_t)(cap + 1) * P->ld * sizeof(double));
+  P->m_cap = cap;
+}
+
+static void ensure_cols(orc_prob *P, int n_new) {
+  if (n_new <= P->n_cap) return;
+  int cap = P->n_cap ? P->n_cap : 8;
+  while (cap < n_new) cap *= 2;
+  for (int i = 1; i <= P->m; i++) {
+    P->A[i] = (double *)xrealloc(P->A[i], (size_t)(cap + 1) * sizeof(double));
+    for (int j = P->n_cap + 1; j <= cap; j++) P->A[i][j] = 0.0;
+  }
+  P->c = (double *)xrealloc(P->c, (size_t)(cap + 1) * sizeof(double));
+  P->kind = (int *)xrealloc(P->kind, (size_t)(cap + 1) * sizeof(int));
+  P->ctype = (int *)xrealloc(P->ctype, (size_t)(cap + 1) * sizeof(int));
+  P->clb = (double *)xrealloc(P->clb, (size_t)(cap + 1) * sizeof(double));
+  P->cub = (double *)xrealloc(P->cub, (size_t)(cap + 1) * sizeof(double));
+  P->nvar = (int *)xrealloc(P->nvar, (size_t)(cap + 1) * sizeof(int));
+  P->nflag = (int *)xrealloc(P->nflag, (size_t)(cap + 1) * sizeof(int));
+  P->nlb = (double *)xrealloc(P->nlb, (size_t)(cap + 1) * sizeof(double));
+  P->nub = (double *)xrealloc(P->nub, (size_t)(cap + 1) * sizeof(double));
+  if (P->cname) {
+    P->cname = (char **)xrealloc(P->cname, (size_t)(cap + 1) * sizeof(char *));
+    for (int j = P->n_cap + 1; j <= cap; j++) P->cname[j] = NULL;
+  }
+  P->n_cap = cap;
+}
+
+void orc_copy_prob(orc_prob *dst, const orc_prob *src, int names) {
+  /* glp_copy_prob (bs.cpp:116, util.cpp:34): deep copy incl. basis and last solution
+     [GLPK-recalled]; names iff `names` is ON. */
+  if (dst == src) fault("copy_prob: dst == src");
+  orc_erase_prob(dst);
+  ensure_rows(dst, src->m);
+  ensure_cols(dst, src->n);
+  dst->m = src->m;
+  dst->n = src->n;
+  dst->dir = src->dir;
+  for (int i = 1; i <= src->m; i++) {
+    dst->A[i] = (double *)xcalloc((size_t)dst->n_cap + 1, sizeof(double));
+    memcpy(dst->A[i], src->A[i], (size_t)(src->n + 1) * sizeof(double));
+    dst->rtype[i] = src->rtype[i];
+    dst->rlb[i] = src->rlb[i];
+    dst->rub[i] = src->rub[i];
+  }
+  memcpy(dst->c, src->c, (size_t)(src->n + 1) * sizeof(double));
+  for (int j = 1; j <= src->n; j++) {
+    dst->kind[j] = src->kind[j];
+    dst->ctype[j] = src->ctype[j];
+    dst->clb[j] = src->clb[j];
+    dst->cub[j] = src->cub[j];
+  }
+  if (names && src->cname) {
+    dst->cname = (char **)xcalloc((size_t)dst->n_cap + 1, sizeof(char *));
+    for (int j = 1; j <= src->n; j++)
+      if (src->cname[j]) dst->cname[j] = strdup(src->cname[j]);
+  }
+  dst->valid = src->valid;
+  dst->status = src->status;
+  dst->it_cnt = src->it_cnt;
+  if (src->valid) {
+    dst->ld = src->ld;
+    dst->T = (double *)xcalloc((size_t)(dst->m_cap + 1) * dst->ld, sizeof(double));
+    memcpy(dst->T, src->T, (size_t)(src->m + 1) * src->ld * sizeof(double));
+    for (int i = 1; i <= src->m; i++) {
+      dst->bvar[i] = src->bvar[i];
+      dst->blb[i] = src->blb[i];
+      dst->bub[i] = src->bub[i];
+    }
+    for (int j = 1; j <= src->n; j++) {
+      dst->nvar[j] = src->nvar[j];
+      dst->nflag[j] = src->nflag[j];
+      dst->nlb[j] = src->nlb[j];
+      dst->nub[j] = src->nub[j];
+    }
+  }
+}
+
+/* -------------------------------------------------------- tableau utilities */
+#define TT(P, i, j) ((P)->T[(size_t)(i) * (P)->ld + (j)])
+
+/* out[j] (j=0..n) = base[j] + sum over 64-row chunks (in order) of the fma-chain
+   sum_{i in chunk, w[i] != 0} w[i]*T[i][j].  Same order in the HIP kernel k_rowcomb. */
+static void rowcomb(const orc_prob *P, const double *w, const double *base, double *out) {
+  int m = P->m, n = P->n;
+  for (int j = 0; j <= n; j++) out[j] = base ? base[j] : 0.0;
+  for (int c0 = 1; c0 <= m; c0 += ROWCOMB_CHUNK) {
+    int c1 = c0 + ROWCOMB_CHUNK - 1;
+    if (c1 > m) c1 = m;
+    for (int j = 0; j <= n; j++) {
+      double acc = 0.0;
+      for (int i = c0; i <= c1; i++)
+        if (w[i] != 0.0) acc = fma(w[i], TT(P, i, j), acc);
+      out[j] = out[j] + acc;
+    }
+  }
+}
+
+/* position of variable k: +i if basic in row i, -j if non-basic in column j */
+static int var_pos(const orc_prob *P, int k) {
+  for (int i = 1; i <= P->m; i++)
+    if (P->bvar[i] == k) return i;
+  for (int j = 1; j <= P->n; j++)
+    if (P->nvar[j] == k) return -j;
+  fault("var_pos: variable not found");
+  return 0;
+}
+
+static void build_slack_tableau(orc_prob *P) {
+  int m = P->m, n = P->n;
+  P->ld = ((n + 1 + 7) / 8) * 8;
+  free(P->T);
+  P->T = (double *)xcalloc((size_t)(P->m_cap + 1) * P->ld, sizeof(double));
+  for (int j = 1; j <= n; j++) {
+    P->nvar[j] = m + j;
+    P->nflag[j] = std_flag(P->ctype[j]);
+    P->nlb[j] = P->clb[j];
+    P->nub[j] = P->cub[j];
+  }
+  for (int i = 1; i <= m; i++) {
+    P->bvar[i] = i;
+    P->blb[i] = P->rlb[i];
+    P->bub[i] = P->rub[i];
+  }
+  double z = P->c[0];
+  for (int j = 1; j <= n; j++) {
+    double x = nb_value(P->nflag[j], P->nlb[j], P->nub[j]);
+    TT(P, 0, j) = P->c[j];
+    if (x != 0.0) z = fma(P->c[j], x, z);
+  }
+  TT(P, 0, 0) = z;
+  for (int i = 1; i <= m; i++) {
+    double acc = 0.0;
+    for (int j = 1; j <= n; j++) {
+      double a = P->A[i][j];
+      double x = nb_value(P->nflag[j], P->nlb[j], P->nub[j]);
+      TT(P, i, j) = a;
+      if (x != 0.0) acc = fma(a, x, acc);
+    }
+    TT(P, i, 0) = acc;
+  }
+  P->valid = 1;
+  P->status = ORC_UNDEF;
+}
+
+/* a non-basic variable in column jj changes value by delta: beta += T[:,jj]*delta */
+static void shift_nonbasic(orc_prob *P, int jj, double delta) {
+  for (int i = 0; i <= P->m; i++) TT(P, i, 0) = fma(TT(P, i, jj), delta, TT(P, i, 0));
+}
+
+static void apply_bounds_to_engine(orc_prob *P, int k, int type, double lb, double ub) {
+  if (!P->valid) return;
+  int pos = var_pos(P, k);
+  if (pos > 0) {
+    P->blb[pos] = lb;
+    P->bub[pos] = ub;
+  } else {
+    int jj = -pos;
+    double xo = nb_value(P->nflag[jj], P->nlb[jj], P->nub[jj]);
+    int flag;
+    switch (type) {
+      case ORC_FR: flag = ORC_NF; break;
+      case ORC_LO: flag = ORC_NL; break;
+      case ORC_UP: flag = ORC_NU; break;
+      case ORC_DB: flag = (P->nflag[jj] == ORC_NU) ? ORC_NU : ORC_NL; break;
+      default: flag = ORC_NS; break;
+    }
+    P->nlb[jj] = lb;
+    P->nub[jj] = ub;
+    P->nflag[jj] = flag;
+    double xn = nb_value(flag, lb, ub);
+    if (xn != xo) shift_nonbasic(P, jj, xn - xo);
+  }
+  P->status = ORC_UNDEF;
+}
+
+/* ----------------------------------------------------------- build / modify */
+void orc_set_obj_dir(orc_prob *P, int dir) {
+  if (dir != ORC_MIN && dir != ORC_MAX) fault("set_obj_dir: invalid direction");
+  P->dir = dir;
+  P->status = ORC_UNDEF;
+}
+
+int orc_add_rows(orc_prob *P, int nrs) {
+  if (nrs < 1) fault("add_rows: invalid count");
+  int first = P->m + 1;
+  ensure_rows(P, P->m + nrs);
+  for (int i = first; i < first + nrs; i++) {
+    P->A[i] = (double *)xcalloc((size_t)P->n_cap + 1, sizeof(double));
+    P->rtype[i] = ORC_FR;
+    P->rlb[i] = -INF;
+    P->rub[i] = INF;
+    if (P->valid) {
+      /* new auxiliary variable enters the basis in its own new row [GLPK-recalled:
+         glp_add_rows creates rows with status GLP_BS]; an empty row is identically 0 */
+      P->bvar[i] = i;
+      P->blb[i] = -INF;
+      P->bub[i] = INF;
+      for (int j = 0; j <= P->n; j++) TT(P, i, j) = 0.0;
+    }
+  }
+  P->m += nrs;
+  if (P->valid) {
+    /* structural variable numbers shift by nrs */
+    for (int i = 1; i < first; i++)
+      if (P->bvar[i] >= first) P->bvar[i] += nrs;
+    for (int j = 1; j <= P->n; j++)
+      if (P->nvar[j] >= first) P->nvar[j] += nrs;
+  }
+  P->status = ORC_UNDEF;
+  return first;
+}
+
+int orc_add_cols(orc_prob *P, int ncs) {
+  if (ncs < 1) fault("add_cols: invalid count");
+  int first = P->n + 1;
+  ensure_cols(P, P->n + ncs);
+  for (int j = first; j < first + ncs; j++) {
+    P->c[j] = 0.0;
+    P->kind[j] = ORC_CV;
+    P->ctype[j] = ORC_FX; /* GLPK default column: fixed at 0 [GLPK-recalled] */
+    P->clb[j] = 0.0;
+    P->cub[j] = 0.0;
+    for (int i = 1; i <= P->m; i++) P->A[i][j] = 0.0;
+  }
+  P->n += ncs;
+  P->valid = 0; /* engine state is rebuilt from the slack basis */
+  P->status = ORC_UNDEF;
+  return first;
+}
+
+void orc_set_row_bnds(orc_prob *P, int i, int type, double lb, double ub) {
+  if (i < 1 || i > P->m) fault("set_row_bnds: row out of range");
+  P->rtype[i] = type;
+  norm_bounds(type, lb, ub, &P->rlb[i], &P->rub[i]);
+  apply_bounds_to_engine(P, i, type, P->rlb[i], P->rub[i]);
+}
+
+void orc_set_col_bnds(orc_prob *P, int j, int type, double lb, double ub) {
+  if (j < 1 || j > P->n) fault("set_col_bnds: column out of range");
+  P->ctype[j] = type;
+  norm_bounds(type, lb, ub, &P->clb[j], &P->cub[j]);
+  apply_bounds_to_engine(P, P->m + j, type, P->clb[j], P->cub[j]);
+}
+
+static void recompute_cost_row(orc_prob *P) {
+  /* d = c_N + c_B^T T ; z = c0 + c_B^T beta + c_N^T x_N */
+  int m = P->m, n = P->n;
+  double *w = (double *)xcalloc((size_t)m + 1, sizeof(double));
+  double *base = (double *)xcalloc((size_t)n + 1, sizeof(double));
+  double *out = (double *)xcalloc((size_t)n + 1, sizeof(double));
+  for (int i = 1; i <= m; i++) w[i] = (P->bvar[i] > m) ? P->c[P->bvar[i] - m] : 0.0;
+  double z = P->c[0];
+  for (int j = 1; j <= n; j++) {
+    double cj = (P->nvar[j] > m) ? P->c[P->nvar[j] - m] : 0.0;
+    double x = nb_value(P->nflag[j], P->nlb[j], P->nub[j]);
+    base[j] = cj;
+    if (x != 0.0 && cj != 0.0) z = fma(cj, x, z);
+  }
+  base[0] = z;
+  rowcomb(P, w, base, out);
+  for (int j = 0; j <= n; j++) TT(P, 0, j) = out[j];
+  free(w); free(base); free(out);
+}
+
+void orc_set_obj_coef(orc_prob *P, int j, double coef) {
+  if (j < 0 || j > P->n) fault("set_obj_coef: column out of range");
+  P->c[j] = coef;
+  if (P->valid) recompute_cost_row(P);
+  P->status = ORC_UNDEF;
+}
+
+void orc_set_mat_row(orc_prob *P, int i, int len, const int *ind, const double *val) {
+  /* cut.cpp:40: 1-based ind/val, element 0 ignored */
+  if (i < 1 || i > P->m) fault("set_mat_row: row out of range");
+  if (len < 0 || len > P->n) fault("set_mat_row: invalid length");
+  for (int j = 1; j <= P->n; j++) P->A[i][j] = 0.0;
+  for (int k = 1; k <= len; k++) {
+    if (ind[k] < 1 || ind[k] > P->n) fault("set_mat_row: column index out of range");
+    P->A[i][ind[k]] = val[k];
+  }
+  if (P->valid) {
+    int pos = var_pos(P, i);
+    if (pos <= 0) {
+      P->valid = 0; /* row of a non-basic auxiliary changed: rebuild from the slack basis */
+    } else {
+      /* x_i = sum_j v_j x_(m+j): substitute the basic structurals by their tableau rows */
+      int m = P->m, n = P->n;
+      double *w = (double *)xcalloc((size_t)m + 1, sizeof(double));
+      double *base = (double *)xcalloc((size_t)n + 1, sizeof(double));
+      double *out = (double *)xcalloc((size_t)n + 1, sizeof(double));
+      for (int r = 1; r <= m; r++)
+        if (r != pos && P->bvar[r] > m) w[r] = P->A[i][P->bvar[r] - m];
+      double b0 = 0.0;
+      for (int jj = 1; jj <= n; jj++) {
+        if (P->nvar[jj] > m) {
+          double v = P->A[i][P->nvar[jj] - m];
+          double x = nb_value(P->nflag[jj], P->nlb[jj], P->nub[jj]);
+          base[jj] = v;
+          if (x != 0.0 && v != 0.0) b0 = fma(v, x, b0);
+        }
+      }
+      base[0] = b0;
+      rowcomb(P, w, base, out);
+      for (int jj = 0; jj <= n; jj++) TT(P, pos, jj) = out[jj];
+      free(w); free(base); free(out);
+    }
+  }
+  P->status = ORC_UNDEF;
+}
+
+void orc_set_col_kind(orc_prob *P, int j, int kind) {
+  if (j < 1 || j > P->n) fault("set_col_kind: column out of range");
+  if (kind == ORC_BV) {
+    /* GLPK: BV = IV with bounds [0,1] [GLPK-recalled] */
+    P->kind[j] = ORC_IV;
+    orc_set_col_bnds(P, j, ORC_DB, 0.0, 1.0);
+  } else {
+    P->kind[j] = kind;
+  }
+}
+
+void orc_set_col_name(orc_prob *P, int j, const char *name) {
+  if (j < 1 || j > P->n) fault("set_col_name: column out of range");
+  if (!P->cname) P->cname = (char **)xcalloc((size_t)P->n_cap + 1, sizeof(char *));
+  free(P->cname[j]);
+  P->cname[j] = name ? strdup(name) : NULL;
+}
+
+const char *orc_get_col_name(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_name: column out of range");
+  return P->cname ? P->cname[j] : NULL;
+}
+
+int orc_load_dense(orc_prob *P, int m, int n, const double *A, const double *b, const double *c) {
+  /* fast-path loader: max c'x, Ax <= b, x >= 0 (SURVEY.md section 8(d) generator) */
+  orc_erase_prob(P);
+  orc_set_obj_dir(P, ORC_MAX);
+  orc_add_cols(P, n);
+  orc_add_rows(P, m);
+  for (int j = 1; j <= n; j++) {
+    P->c[j] = c[j - 1];
+    P->ctype[j] = ORC_LO;
+    P->clb[j] = 0.0;
+    P->cub[j] = INF;
+  }
+  for (int i = 1; i <= m; i++) {
+    memcpy(&P->A[i][1], &A[(size_t)(i - 1) * n], (size_t)n * sizeof(double));
+    P->rtype[i] = ORC_UP;
+    P->rlb[i] = -INF;
+    P->rub[i] = b[i - 1];
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------ simplex steps */
+typedef struct {
+  double tol_bnd, tol_dj, tol_piv;
+  int budget; /* remaining pivots, <0 = unlimited */
+} ctl_t;
+
+/* Dantzig pricing on row `cost` (length n+1, entries 1..n), maximisation sense already
+   folded in through sgn.  Returns column q (0 = none), *sdir = +1 (increase) / -1. */
+static int price(const orc_prob *P, const double *cost, double sgn, double tol, int *sdir) {
+  int q = 0;
+  double best = 0.0;
+  for (int j = 1; j <= P->n; j++) {
+    int f = P->nflag[j];
+    if (f == ORC_NS) continue;
+    double dj = sgn * cost[j];
+    int up = (f == ORC_NL || f == ORC_NF) && dj > tol;
+    int dn = (f == ORC_NU || f == ORC_NF) && dj < -tol;
+    if (!up && !dn) continue;
+    double sc = fabs(dj);
+    if (q == 0 || sc > best) { /* strict > keeps the lowest j on ties */
+      best = sc;
+      q = j;
+      *sdir = up ? +1 : -1;
+    }
+  }
+  return q;
+}
+
+/* lexicographic candidate compare: smaller t, then larger |a|, then smaller index */
+static int better(double t, double mag, int idx, double bt, double bmag, int bidx) {
+  if (bidx == 0) return 1;
+  if (t < bt) return 1;
+  if (t > bt) return 0;
+  if (mag > bmag) return 1;
+  if (mag < bmag) return 0;
+  return idx < bidx;
+}
+
+/* row of maximal primal infeasibility (0 = feasible); *to_upper = 1 if above ub */
+static int select_infeasible_row(const orc_prob *P, double tol_bnd, int *to_upper) {
+  int p = 0;
+  double best = 0.0;
+  for (int i = 1; i <= P->m; i++) {
+    double beta = TT(P, i, 0);
+    double lb = P->blb[i], ub = P->bub[i];
+    double viol = 0.0;
+    int up = 0;
+    if (lb > -INF && beta < lb - tol_bnd * (1.0 + fabs(lb))) viol = lb - beta;
+    if (ub < INF && beta > ub + tol_bnd * (1.0 + fabs(ub))) {
+      viol = beta - ub;
+      up = 1;
+    }
+    if (viol > 0.0 && (p == 0 || viol > best)) {
+      best = viol;
+      p = i;
+      *to_upper = up;
+    }
+  }
+  return p;
+}
+
+/* Gauss-Jordan pivot on (p,q).  bound = value the leaving variable lands on,
+   leave_flag = its non-basic status afterwards. */
+static void pivot(orc_prob *P, int p, int q, double bound, int leave_flag) {
+  int m = P->m, n = P->n, ld = P->ld;
+  double *rowp = &TT(P, p, 0);
+  double piv = rowp[q];
+  double xq = nb_value(P->nflag[q], P->nlb[q], P->nub[q]);
+  double *s = (double *)xcalloc((size_t)n + 1, sizeof(double));
+  s[0] = (rowp[0] - bound) / piv;
+  for (int j = 1; j <= n; j++) s[j] = rowp[j] / piv;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i <= m; i++) {
+    if (i == p) continue;
+    double *row = &P->T[(size_t)i * ld];
+    double ci = row[q];
+    double nci = -ci;
+    for (int j = 0; j <= n; j++) row[j] = fma(nci, s[j], row[j]);
+    row[q] = ci / piv;
+  }
+  for (int j = 1; j <= n; j++) rowp[j] = -s[j];
+  rowp[q] = 1.0 / piv;
+  rowp[0] = xq - s[0];
+  free(s);
+  /* swap basis bookkeeping */
+  int kv = P->bvar[p];
+  double klb = P->blb[p], kub = P->bub[p];
+  P->bvar[p] = P->nvar[q];
+  P->blb[p] = P->nlb[q];
+  P->bub[p] = P->nub[q];
+  P->nvar[q] = kv;
+  P->nlb[q] = klb;
+  P->nub[q] = kub;
+  P->nflag[q] = leave_flag;
+  P->it_cnt++;
+}
+
+static int leave_flag_for(double lb, double ub, int to_upper) {
+  if (lb == ub) return ORC_NS;
+  return to_upper ? ORC_NU : ORC_NL;
+}
+
+enum { R_OPT = 1, R_UNBND, R_NOFEAS, R_ITLIM, R_PFEAS, R_FAIL };
+
+/* One primal iteration for entering column q moving in direction sdir.
+   phase1: g[i] != 0 marks infeasible basics (+1 below lb, -1 above ub).
+   Returns 0 = pivot/flip done, R_UNBND = no blocking row. */
+static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
+  int m = P->m;
+  int p = 0, p_up = 0;
+  double bt = 0.0, bmag = 0.0;
+  for (int i = 1; i <= m; i++) {
+    double a = TT(P, i, q);
+    double aa = (sdir > 0) ? a : -a;
+    double beta = TT(P, i, 0);
+    double t;
+    int up;
+    if (aa > ctl->tol_piv) { /* basic variable increases */
+      if (g && g[i] < 0) continue;               /* above ub, moving further away */
+      if (g && g[i] > 0) { t = (P->blb[i] - beta) / aa; up = 0; } /* reaches lb from below */
+      else {
+        if (!(P->bub[i] < INF)) continue;
+        t = (P->bub[i] - beta) / aa;
+        up = 1;
+      }
+    } else if (aa < -ctl->tol_piv) { /* decreases */
+      if (g && g[i] > 0) continue;
+      if (g && g[i] < 0) { t = (beta - P->bub[i]) / (-aa); up = 1; }
+      else {
+        if (!(P->blb[i] > -INF)) continue;
+        t = (beta - P->blb[i]) / (-aa);
+        up = 0;
+      }
+    } else
+      continue;
+    if (t < 0.0) t = 0.0;
+    double mag = fabs(a);
+    if (better(t, mag, i, bt, bmag, p)) {
+      bt = t;
+      bmag = mag;
+      p = i;
+      p_up = up;
+    }
+  }
+  /* bound flip of the entering variable itself */
+  if (P->nlb[q] > -INF && P->nub[q] < INF && P->nflag[q] != ORC_NF) {
+    double tf = P->nub[q] - P->nlb[q];
+    if (p == 0 || tf <= bt) {
+      double delta = (sdir > 0) ? tf : -tf;
+      shift_nonbasic(P, q, delta);
+      P->nflag[q] = (sdir > 0) ? ORC_NU : ORC_NL;
+      return 0;
+    }
+  }
+  if (p == 0) return R_UNBND;
+  double bound = p_up ? P->bub[p] : P->blb[p];
+  pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], p_up));
+  if (ctl->budget > 0) ctl->budget--;
+  return 0;
+}
+
+static int primal_phase2(orc_prob *P, ctl_t *ctl) {
+  double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
+  for (;;) {
+    int sdir = 0;
+    int q = price(P, &TT(P, 0, 0), sgn, ctl->tol_dj, &sdir);
+    if (q == 0) return R_OPT;
+    if (ctl->budget == 0) return R_ITLIM;
+    int r = primal_step(P, ctl, q, sdir, NULL);
+    if (r) return r;
+  }
+}
+
+static int primal_phase1(orc_prob *P, ctl_t *ctl) {
+  int m = P->m, n = P->n;
+  int *g = (int *)xcalloc((size_t)m + 1, sizeof(int));
+  double *w = (double *)xcalloc((size_t)m + 1, sizeof(double));
+  double *cost = (double *)xcalloc((size_t)n + 1, sizeof(double));
+  int ret;
+  for (;;) {
+    int ninf = 0;
+    for (int i = 1; i <= m; i++) {
+      double beta = TT(P, i, 0), lb = P->blb[i], ub = P->bub[i];
+      g[i] = 0;
+      if (lb > -INF && beta < lb - ctl->tol_bnd * (1.0 + fabs(lb))) g[i] = 1;
+      if (ub < INF && beta > ub + ctl->tol_bnd * (1.0 + fabs(ub))) g[i] = -1;
+      w[i] = (double)g[i];
+      if (g[i]) ninf++;
+    }
+    if (ninf == 0) { ret = R_PFEAS; break; }
+    rowcomb(P, w, NULL, cost);
+    int sdir = 0;
+    int q = price(P, cost, 1.0, ctl->tol_dj, &sdir);
+    if (q == 0) { ret = R_NOFEAS; break; }
+    if (ctl->budget == 0) { ret = R_ITLIM; break; }
+    int r = primal_step(P, ctl, q, sdir, g);
+    if (r == R_UNBND) { ret = R_FAIL; break; }
+  }
+  free(g); free(w); free(cost);
+  return ret;
+}
+
+static int dual_simplex(orc_prob *P, ctl_t *ctl) {
+  int n = P->n;
+  double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
+  for (;;) {
+    int to_upper = 0;
+    int p = select_infeasible_row(P, ctl->tol_bnd, &to_upper);
+    if (p == 0) return R_PFEAS;
+    if (ctl->budget == 0) return R_ITLIM;
+    int need_inc = !to_upper; /* below lb: the basic variable must increase */
+    int q = 0;
+    double br = 0.0, bmag = 0.0;
+    for (int j = 1; j <= n; j++) {
+      int f = P->nflag[j];
+      if (f == ORC_NS) continue;
+      double a = TT(P, p, j);
+      double aa = need_inc ? a : -a; /* > 0: raising x_j helps; < 0: lowering x_j helps */
+      double d = sgn * TT(P, 0, j);
+      double r;
+      if (aa > ctl->tol_piv && (f == ORC_NL || f == ORC_NF)) {
+        r = (f == ORC_NF) ? fabs(d) : (d < 0.0 ? -d : 0.0);
+      } else if (aa < -ctl->tol_piv && (f == ORC_NU || f == ORC_NF)) {
+        r = (f == ORC_NF) ? fabs(d) : (d > 0.0 ? d : 0.0);
+      } else
+        continue;
+      double mag = fabs(a);
+      r = r / mag;
+      if (better(r, mag, j, br, bmag, q)) {
+        br = r;
+        bmag = mag;
+        q = j;
+      }
+    }
+    if (q == 0) return R_NOFEAS;
+    double bound = to_upper ? P->bub[p] : P->blb[p];
+    pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], to_upper));
+    if (ctl->budget > 0) ctl->budget--;
+  }
+}
+
+void orc_init_smcp(orc_smcp *parm) {
+  parm->msg_lev = 0;
+  parm->meth = 1;
+  parm->it_lim = -1;
+  parm->tol_bnd = 1e-9;
+  parm->tol_dj = 1e-9;
+  parm->tol_piv = 1e-9;
+}
+
+int orc_simplex(orc_prob *P, const orc_smcp *parm) {
+  orc_smcp dflt;
+  if (!parm) {
+    orc_init_smcp(&dflt);
+    parm = &dflt;
+  }
+  if (P->m < 1 || P->n < 1) {
+    P->status = ORC_UNDEF;
+    return ORC_EFAIL;
+  }
+  if (!P->valid) build_slack_tableau(P);
+  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, parm->it_lim};
+  double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
+  for (int round = 0; round < 64; round++) {
+    int to_upper = 0, sdir = 0;
+    int p = select_infeasible_row(P, ctl.tol_bnd, &to_upper);
+    int r;
+    if (p == 0) {
+      r = primal_phase2(P, &ctl);
+      if (r == R_OPT) {
+        if (select_infeasible_row(P, ctl.tol_bnd, &to_upper) == 0) {
+          P->status = ORC_OPT;
+          return 0;
+        }
+        continue;
+      }
+      if (r == R_UNBND) { P->status = ORC_UNBND; return 0; }
+      P->status = ORC_FEAS;
+      return ORC_EITLIM;
+    }
+    int q = (parm->meth == 2) ? 1 : price(P, &TT(P, 0, 0), sgn, ctl.tol_dj, &sdir);
+    r = (q == 0) ? dual_simplex(P, &ctl) : primal_phase1(P, &ctl);
+    if (r == R_PFEAS) continue;
+    if (r == R_NOFEAS) { P->status = ORC_NOFEAS; return 0; }
+    if (r == R_ITLIM) { P->status = ORC_INFEAS; return ORC_EITLIM; }
+    P->status = ORC_UNDEF;
+    return ORC_EFAIL;
+  }
+  P->status = ORC_UNDEF;
+  return ORC_EFAIL;
+}
+
+/* -------------------------------------------------------------------- query */
+int orc_get_obj_dir(const orc_prob *P) { return P->dir; }
+int orc_get_num_rows(const orc_prob *P) { return P->m; }
+int orc_get_num_cols(const orc_prob *P) { return P->n; }
+int orc_get_num_int(const orc_prob *P) {
+  int k = 0;
+  for (int j = 1; j <= P->n; j++) k += (P->kind[j] == ORC_IV);
+  return k;
+}
+int orc_get_status(const orc_prob *P) { return P->status; }
+double orc_get_obj_val(const orc_prob *P) { return P->valid ? TT(P, 0, 0) : P->c[0]; }
+double orc_get_obj_coef(const orc_prob *P, int j) {
+  if (j < 0 || j > P->n) fault("get_obj_coef: column out of range");
+  return P->c[j];
+}
+
+static double var_prim(const orc_prob *P, int k) {
+  if (!P->valid) return 0.0;
+  int pos = var_pos(P, k);
+  if (pos > 0) return TT(P, pos, 0);
+  return nb_value(P->nflag[-pos], P->nlb[-pos], P->nub[-pos]);
+}
+static double var_dual(const orc_prob *P, int k) {
+  if (!P->valid) return 0.0;
+  int pos = var_pos(P, k);
+  return pos > 0 ? 0.0 : TT(P, 0, -pos);
+}
+static int var_stat(const orc_prob *P, int k, int type) {
+  if (!P->valid) return (k <= P->m) ? ORC_BS : std_flag(type);
+  int pos = var_pos(P, k);
+  return pos > 0 ? ORC_BS : P->nflag[-pos];
+}
+
+double orc_get_col_prim(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_prim: column out of range");
+  return var_prim(P, P->m + j);
+}
+double orc_get_row_prim(const orc_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_prim: row out of range");
+  return var_prim(P, i);
+}
+double orc_get_col_dual(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_dual: column out of range");
+  return var_dual(P, P->m + j);
+}
+double orc_get_row_dual(const orc_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_dual: row out of range");
+  return var_dual(P, i);
+}
+int orc_get_col_stat(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_stat: column out of range");
+  return var_stat(P, P->m + j, P->ctype[j]);
+}
+int orc_get_row_stat(const orc_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_stat: row out of range");
+  return var_stat(P, i, P->rtype[i]);
+}
+int orc_get_col_kind(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_kind: column out of range");
+  /* GLPK reports an integer column with bounds [0,1] as GLP_BV [GLPK-recalled]; this is
+     what makes gmi.cpp:18 reject binaries while util.cpp:444 still branches on them */
+  if (P->kind[j] == ORC_IV && P->ctype[j] == ORC_DB && P->clb[j] == 0.0 && P->cub[j] == 1.0)
+    return ORC_BV;
+  return P->kind[j];
+}
+int orc_get_row_type(const orc_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_type: row out of range");
+  return P->rtype[i];
+}
+/* absent bounds read back as -/+DBL_MAX [GLPK-recalled]; consumed arithmetically at
+   gmi.cpp:73 */
+double orc_get_row_lb(const orc_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_lb: row out of range");
+  return P->rlb[i] == -INF ? -DBL_MAX : P->rlb[i];
+}
+double orc_get_row_ub(const orc_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_ub: row out of range");
+  return P->rub[i] == INF ? DBL_MAX : P->rub[i];
+}
+int orc_get_col_type(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_type: column out of range");
+  return P->ctype[j];
+}
+double orc_get_col_lb(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_lb: column out of range");
+  return P->clb[j] == -INF ? -DBL_MAX : P->clb[j];
+}
+double orc_get_col_ub(const orc_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_ub: column out of range");
+  return P->cub[j] == INF ? DBL_MAX : P->cub[j];
+}
+
+int orc_get_mat_row(const orc_prob *P, int i, int *ind, double *val) {
+  /* non-zeros in ascending column order (GLPK's own order is unobservable here,
+     SURVEY.md section 8(c) "unverifiable hazards") */
+  if (i < 1 || i > P->m) fault("get_mat_row: row out of range");
+  int len = 0;
+  for (int j = 1; j <= P->n; j++) {
+    if (P->A[i][j] != 0.0) {
+      len++;
+      if (ind) ind[len] = j;
+      if (val) val[len] = P->A[i][j];
+    }
+  }
+  return len;
+}
+
+int orc_eval_tab_row(const orc_prob *P, int k, int *ind, double *val) {
+  /* gmi.cpp:36: row of the simplex tableau for basic variable k over the non-basic
+     variables; non-zeros only, in ascending non-basic column position */
+  if (!P->valid) fault("eval_tab_row: basis does not exist");
+  if (k < 1 || k > P->m + P->n) fault("eval_tab_row: variable out of range");
+  int pos = var_pos(P, k);
+  if (pos <= 0) fault("eval_tab_row: variable must be basic");
+  int len = 0;
+  for (int j = 1; j <= P->n; j++) {
+    double a = TT(P, pos, j);
+    if (a != 0.0) {
+      len++;
+      ind[len] = P->nvar[j];
+      val[len] = a;
+    }
+  }
+  return len;
+}
+
+int orc_get_it_cnt(const orc_prob *P) { return P->it_cnt; }
+int orc_term_out(int flag) {
+  int old = g_term_out;
+  g_term_out = flag;
+  return old;
+}
+const char *orc_version(void) { return "mvolps-oracle 1.0 (dense tableau; GLPK-shaped API)"; }
+
+int orc_get_tableau_ld(const orc_prob *P) { return P->ld; }
+int orc_get_tableau(const orc_prob *P, double *out) {
+  if (!P->valid) return -1;
+  for (int i = 0; i <= P->m; i++)
+    memcpy(&out[(size_t)i * (P->n + 1)], &TT(P, i, 0), (size_t)(P->n + 1) * sizeof(double));
+  return 0;
+}
+int orc_get_basis(const orc_prob *P, int *head, int *nb, int *flag) {
+  if (!P->valid) return -1;
+  head[0] = 0;
+  for (int i = 1; i <= P->m; i++) head[i] = P->bvar[i];
+  nb[0] = 0;
+  flag[0] = 0;
+  for (int j = 1; j <= P->n; j++) {
+    nb[j] = P->nvar[j];
+    flag[j] = P->nflag[j];
+  }
+  return 0;
+}

@@ -1,0 +1,118 @@
+"""Python loader for the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from mvolps_amd import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+class BnbParams(C.Structure):
+    _fields_ = [
+        ("var_strat", C.c_int),
+        ("node_strat", C.c_int),
+        ("cut_strat", C.c_int),
+        ("cut_chance", C.c_double),
+        ("loop_limit", C.c_int),
+        ("max_nodes", C.c_int),
+        ("reference_quirks", C.c_int),
+    ]
+
+
+class BnbEvent(C.Structure):
+    _fields_ = [
+        ("type", C.c_int),
+        ("oid", C.c_int),
+        ("pid", C.c_int),
+        ("direction", C.c_int),
+        ("lp_bound", C.c_double),
+        ("sum_infeas", C.c_double),
+        ("n_violated", C.c_int),
+        ("pick", C.c_int),
+    ]
+
+
+class BnbResult(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int),
+        ("parent", C.POINTER(C.c_int)),
+        ("prune", C.POINTER(C.c_int)),
+        ("node_bound", C.POINTER(C.c_double)),
+        ("n_events", C.c_int),
+        ("events", C.POINTER(BnbEvent)),
+        ("count", C.c_int),
+        ("has_incumbent", C.c_int),
+        ("best_lower", C.c_double),
+        ("incumbent_oid", C.c_int),
+        ("n", C.c_int),
+        ("x", C.POINTER(C.c_double)),
+        ("total_pivots", C.c_longlong),
+        ("hit_limit", C.c_int),
+    ]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB
+
+
+_api = None
+
+
+def api():
+    global _api
+    if _api is None:
+        lib = C.CDLL(build())
+        extra = {
+            "getFract": (C.c_double, [C.c_double]),
+            "printInfo": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+            "printInfo_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+            "generateCut3": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+            "bnb_default_params": (None, [C.POINTER(BnbParams)]),
+            "branchAndBound": (C.c_int, [C.c_void_p, C.POINTER(BnbParams), C.POINTER(BnbResult)]),
+            "bnb_free_result": (None, [C.POINTER(BnbResult)]),
+        }
+        _api = capi.LpApi(lib, "orc_", extra)
+    return _api
+
+
+def result_to_dict(res):
+    """Plain-python copy of a BnbResult-shaped struct (oracle's or the product's)."""
+    nn = res.n_nodes
+    out = {
+        "n_nodes": nn,
+        "parent": [res.parent[i] for i in range(1, nn + 1)],
+        "prune": [res.prune[i] for i in range(1, nn + 1)],
+        "node_bound": [res.node_bound[i] for i in range(1, nn + 1)],
+        "events": [
+            (e.type, e.oid, e.pid, e.direction, e.lp_bound, e.sum_infeas, e.n_violated, e.pick)
+            for e in (res.events[k] for k in range(res.n_events))
+        ],
+        "count": res.count,
+        "has_incumbent": res.has_incumbent,
+        "best_lower": res.best_lower,
+        "incumbent_oid": res.incumbent_oid,
+        "x": [res.x[j] for j in range(1, res.n + 1)],
+        "total_pivots": res.total_pivots,
+        "hit_limit": res.hit_limit,
+    }
+    return out
+
+
+def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1):
+    a = api()
+    pr = BnbParams()
+    a.bnb_default_params(C.byref(pr))
+    pr.var_strat, pr.node_strat, pr.cut_strat, pr.max_nodes = var_strat, node_strat, cut_strat, max_nodes
+    pr.reference_quirks = quirks
+    res = BnbResult()
+    a.branchAndBound(prob.h, C.byref(pr), C.byref(res))
+    out = result_to_dict(res)
+    a.bnb_free_result(C.byref(res))
+    return out
