@@ -1,0 +1,146 @@
+/*
+ * mvx.h -- C ABI of the MI355X dense-simplex LP-relaxation engine (libmvolps_amd.so).
+ *
+ * Drop-in boundary: MVOLPS talks to its LP engine only through the GLPK C API
+ * (SURVEY.md section 8(b)).  Every entry point below replaces the glp_* call named next
+ * to it (file:line under /root/reference); semantics, 1-based indexing, "element 0
+ * ignored" array convention, ownership (opaque handle created/destroyed by the caller,
+ * deep copy) and error behaviour (int return codes, never throws; invalid arguments
+ * abort, as GLPK does) follow GLPK's.  Enum VALUES are GLPK's public ones so that a
+ * caller's GLP_* constants can be passed through unchanged.
+ *
+ * Plain C: pointers, ints and doubles only; no C++ or torch types cross this boundary.
+ * The engine needs a gfx950 device: without one every entry point that touches the
+ * engine (mvx_simplex and anything after it) fails loudly (message on stderr + abort).
+ * There is no CPU fallback in this library.
+ */
+#ifndef MVX_H
+#define MVX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* optimisation direction (glp_set_obj_dir / glp_get_obj_dir) */
+#define MVX_MIN 1
+#define MVX_MAX 2
+/* column kind (glp_get_col_kind) */
+#define MVX_CV 1
+#define MVX_IV 2
+#define MVX_BV 3
+/* bound type (glp_set_row_bnds / glp_set_col_bnds) */
+#define MVX_FR 1
+#define MVX_LO 2
+#define MVX_UP 3
+#define MVX_DB 4
+#define MVX_FX 5
+/* basis status (glp_get_row_stat / glp_get_col_stat) */
+#define MVX_BS 1
+#define MVX_NL 2
+#define MVX_NU 3
+#define MVX_NF 4
+#define MVX_NS 5
+/* solution status (glp_get_status) */
+#define MVX_UNDEF 1
+#define MVX_FEAS 2
+#define MVX_INFEAS 3
+#define MVX_NOFEAS 4
+#define MVX_OPT 5
+#define MVX_UNBND 6
+#define MVX_OFF 0
+#define MVX_ON 1
+/* mvx_simplex return codes (glp_simplex) */
+#define MVX_EFAIL 5
+#define MVX_EITLIM 8
+
+typedef struct mvx_prob mvx_prob; /* replaces glp_prob */
+
+/* replaces glp_smcp (only the controls this engine honours) */
+typedef struct {
+  int msg_lev;
+  int meth;       /* 1 = automatic (primal / dual / phase 1 from the basis at hand) */
+  int it_lim;     /* pivot limit for this call, < 0 = none */
+  double tol_bnd; /* primal feasibility tolerance, relative: tol * (1 + |bound|) */
+  double tol_dj;  /* dual feasibility tolerance, absolute */
+  double tol_piv; /* pivot magnitude tolerance, absolute */
+} mvx_smcp;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+mvx_prob *mvx_create_prob(void);   /* glp_create_prob  bs.cpp:89,115; util.cpp:33,281 */
+void mvx_erase_prob(mvx_prob *P);  /* glp_erase_prob   bs.cpp:114 */
+void mvx_delete_prob(mvx_prob *P); /* glp_delete_prob  util.cpp:41 */
+/* glp_copy_prob bs.cpp:116; util.cpp:34 -- deep copy incl. basis, tableau and solution;
+   the device tableau is cloned device-to-device */
+void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names);
+
+/* ---- build / modify ----------------------------------------------------------- */
+void mvx_set_obj_dir(mvx_prob *P, int dir);                                  /* util.cpp:58 */
+int mvx_add_rows(mvx_prob *P, int nrs);                                      /* cut.cpp:23 */
+int mvx_add_cols(mvx_prob *P, int ncs);                                      /* (readers) */
+void mvx_set_row_bnds(mvx_prob *P, int i, int type, double lb, double ub);   /* cut.cpp:43 */
+void mvx_set_col_bnds(mvx_prob *P, int j, int type, double lb, double ub);   /* bs.cpp:274,282 */
+void mvx_set_obj_coef(mvx_prob *P, int j, double coef);                      /* util.cpp:55 */
+void mvx_set_mat_row(mvx_prob *P, int i, int len, const int *ind, const double *val); /* cut.cpp:40 */
+void mvx_set_col_kind(mvx_prob *P, int j, int kind);                         /* (readers) */
+void mvx_set_col_name(mvx_prob *P, int j, const char *name);                 /* (readers) */
+/* dense fast path: max c'x, Ax <= b, x >= 0; A row-major m x n */
+int mvx_load_dense(mvx_prob *P, int m, int n, const double *A, const double *b, const double *c);
+
+/* ---- solve -------------------------------------------------------------------- */
+void mvx_init_smcp(mvx_smcp *parm);                /* glp_init_smcp */
+int mvx_simplex(mvx_prob *P, const mvx_smcp *parm); /* glp_simplex bs.cpp:117,279,287;
+                                                       BranchAndBound.cpp:52,134,141 */
+
+/* ---- query -------------------------------------------------------------------- */
+int mvx_get_obj_dir(const mvx_prob *P);               /* util.cpp:51 */
+int mvx_get_num_rows(const mvx_prob *P);              /* gmi.cpp:15 */
+int mvx_get_num_cols(const mvx_prob *P);              /* gmi.cpp:16; bs.cpp:181,250 */
+int mvx_get_num_int(const mvx_prob *P);               /* util.cpp:299 */
+int mvx_get_status(const mvx_prob *P);                /* util.cpp:423 */
+double mvx_get_obj_val(const mvx_prob *P);            /* bs.cpp:125,156,190,210,280,288 */
+double mvx_get_obj_coef(const mvx_prob *P, int j);    /* bs.cpp:182,190; util.cpp:437,455 */
+double mvx_get_col_prim(const mvx_prob *P, int j);    /* bs.cpp:182,232,261; gmi.cpp:37 */
+double mvx_get_row_prim(const mvx_prob *P, int i);
+double mvx_get_col_dual(const mvx_prob *P, int j);
+double mvx_get_row_dual(const mvx_prob *P, int i);
+int mvx_get_col_stat(const mvx_prob *P, int j);       /* gmi.cpp:23,50 */
+int mvx_get_row_stat(const mvx_prob *P, int i);       /* gmi.cpp:45 */
+int mvx_get_col_kind(const mvx_prob *P, int j);       /* gmi.cpp:18,51; util.cpp:444 */
+int mvx_get_row_type(const mvx_prob *P, int i);       /* util.cpp:377 */
+double mvx_get_row_lb(const mvx_prob *P, int i);      /* util.cpp:378 */
+double mvx_get_row_ub(const mvx_prob *P, int i);      /* gmi.cpp:47 */
+int mvx_get_col_type(const mvx_prob *P, int j);       /* util.cpp:319 */
+double mvx_get_col_lb(const mvx_prob *P, int j);      /* util.cpp:320 */
+double mvx_get_col_ub(const mvx_prob *P, int j);      /* gmi.cpp:52 */
+const char *mvx_get_col_name(const mvx_prob *P, int j);
+int mvx_get_mat_row(const mvx_prob *P, int i, int *ind, double *val);  /* gmi.cpp:84 */
+int mvx_eval_tab_row(const mvx_prob *P, int k, int *ind, double *val); /* gmi.cpp:36 */
+int mvx_get_it_cnt(const mvx_prob *P);
+int mvx_term_out(int flag);      /* glp_term_out 2test.cpp:45,53,62 */
+const char *mvx_version(void);   /* glp_version  util.cpp:278 */
+
+/* ---- engine-state access (parity tests, visualisers) --------------------------- */
+int mvx_get_tableau_ld(const mvx_prob *P);
+int mvx_get_tableau(const mvx_prob *P, double *out); /* (m+1) x (n+1), packed row-major */
+int mvx_get_basis(const mvx_prob *P, int *head, int *nb, int *flag);
+
+/* ---- device / measurement ------------------------------------------------------ */
+/* number of visible HIP devices (0 when none); never aborts */
+int mvx_device_count(void);
+/* bind this process to device `dev` (one process per GPU); 0 on success */
+int mvx_set_device(int dev);
+/* HIP-event timing on the engine's own stream: accumulated milliseconds and launch count
+   of the rank-1 update kernel since the last reset (only collected while enabled) */
+void mvx_profile_enable(int on);
+void mvx_profile_reset(void);
+double mvx_profile_update_ms(void);
+long long mvx_profile_update_launches(void);
+/* wall time (ms, HIP events on the engine stream) of the last mvx_simplex call's device work */
+double mvx_last_solve_ms(const mvx_prob *P);
+/* block until all work queued on the engine stream has finished */
+void mvx_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

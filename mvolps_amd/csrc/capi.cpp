@@ -1,0 +1,407 @@
+// capi.cpp -- the C ABI (include/mvx.h): problem model on the host, GLPK-shaped edit and
+// query semantics, dispatch into the device engine.  Replaces the glp_* surface MVOLPS
+// binds; each function cites its reference call site in mvx.h.
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "engine.hpp"
+
+using mvx::RowPtr;
+
+static const double INF = HUGE_VAL;
+static int g_term_out = 1;
+
+static void fault(const char *msg) {
+  // GLPK aborts on invalid arguments [GLPK-recalled]; same contract here
+  std::fprintf(stderr, "mvx: %s\n", msg);
+  std::abort();
+}
+
+static void norm_bounds(int type, double lb, double ub, double *olb, double *oub) {
+  switch (type) {
+    case MVX_FR: *olb = -INF; *oub = INF; break;
+    case MVX_LO: *olb = lb; *oub = INF; break;
+    case MVX_UP: *olb = -INF; *oub = ub; break;
+    case MVX_DB: *olb = lb; *oub = ub; break;
+    case MVX_FX: *olb = lb; *oub = lb; break;
+    default: fault("invalid bound type");
+  }
+}
+static int std_flag(int type) {
+  switch (type) {
+    case MVX_FR: return MVX_NF;
+    case MVX_LO: return MVX_NL;
+    case MVX_UP: return MVX_NU;
+    case MVX_DB: return MVX_NL;
+    default: return MVX_NS;
+  }
+}
+static double nb_value(int flag, double lb, double ub) {
+  switch (flag) {
+    case MVX_NL: return lb;
+    case MVX_NU: return ub;
+    case MVX_NS: return lb;
+    default: return 0.0;
+  }
+}
+
+static void reset_model(mvx_prob *P) {
+  P->m = P->n = 0;
+  P->dir = MVX_MIN; // GLPK default [GLPK-recalled]
+  P->A.assign(1, RowPtr());
+  P->c.assign(1, 0.0);
+  P->kind.assign(1, 0);
+  P->cname.clear();
+  P->rtype.assign(1, 0); P->rlb.assign(1, 0.0); P->rub.assign(1, 0.0);
+  P->ctype.assign(1, 0); P->clb.assign(1, 0.0); P->cub.assign(1, 0.0);
+  P->valid = false;
+  P->status = MVX_UNDEF;
+  P->it_cnt = 0;
+  P->last_ms = 0.0;
+  P->bvar.clear(); P->nvar.clear(); P->nflag.clear(); P->pos.clear();
+  P->sol_fresh = false;
+  P->beta.clear(); P->dj.clear();
+}
+
+extern "C" {
+
+mvx_prob *mvx_create_prob(void) {
+  mvx_prob *P = new mvx_prob();
+  reset_model(P);
+  return P;
+}
+
+void mvx_erase_prob(mvx_prob *P) {
+  mvx::release_device(P);
+  reset_model(P);
+}
+
+void mvx_delete_prob(mvx_prob *P) {
+  if (!P) return;
+  mvx::release_device(P);
+  delete P;
+}
+
+void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
+  if (dst == src) fault("copy_prob: dst == src");
+  mvx::release_device(dst);
+  // host model: matrix rows are shared (immutable, copy-on-write in set_mat_row)
+  dst->m = src->m; dst->n = src->n; dst->dir = src->dir;
+  dst->A = src->A;
+  dst->c = src->c; dst->kind = src->kind;
+  if (names) dst->cname = src->cname; else dst->cname.clear();
+  dst->rtype = src->rtype; dst->rlb = src->rlb; dst->rub = src->rub;
+  dst->ctype = src->ctype; dst->clb = src->clb; dst->cub = src->cub;
+  dst->status = src->status; dst->it_cnt = src->it_cnt; dst->last_ms = 0.0;
+  dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
+  dst->sol_fresh = src->sol_fresh; dst->beta = src->beta; dst->dj = src->dj;
+  mvx::engine_copy(dst, src);
+}
+
+void mvx_set_obj_dir(mvx_prob *P, int dir) {
+  if (dir != MVX_MIN && dir != MVX_MAX) fault("set_obj_dir: invalid direction");
+  P->dir = dir;
+  P->status = MVX_UNDEF;
+}
+
+int mvx_add_rows(mvx_prob *P, int nrs) {
+  if (nrs < 1) fault("add_rows: invalid count");
+  const int first = P->m + 1;
+  for (int r = 0; r < nrs; r++) {
+    P->A.push_back(std::make_shared<std::vector<double>>((size_t)P->n + 1, 0.0));
+    P->rtype.push_back(MVX_FR);
+    P->rlb.push_back(-INF);
+    P->rub.push_back(INF);
+  }
+  P->m += nrs;
+  if (P->valid) mvx::engine_add_rows(P, first, nrs);
+  P->status = MVX_UNDEF;
+  return first;
+}
+
+int mvx_add_cols(mvx_prob *P, int ncs) {
+  if (ncs < 1) fault("add_cols: invalid count");
+  const int first = P->n + 1;
+  P->n += ncs;
+  P->c.resize((size_t)P->n + 1, 0.0);
+  P->kind.resize((size_t)P->n + 1, MVX_CV);
+  P->ctype.resize((size_t)P->n + 1, MVX_FX); // GLPK default column: fixed at 0 [GLPK-recalled]
+  P->clb.resize((size_t)P->n + 1, 0.0);
+  P->cub.resize((size_t)P->n + 1, 0.0);
+  if (!P->cname.empty()) P->cname.resize((size_t)P->n + 1);
+  for (int i = 1; i <= P->m; i++) {
+    auto row = std::make_shared<std::vector<double>>(*P->A[i]);
+    row->resize((size_t)P->n + 1, 0.0);
+    P->A[i] = row;
+  }
+  if (P->valid) mvx::engine_invalidate(P);
+  P->status = MVX_UNDEF;
+  return first;
+}
+
+void mvx_set_row_bnds(mvx_prob *P, int i, int type, double lb, double ub) {
+  if (i < 1 || i > P->m) fault("set_row_bnds: row out of range");
+  const double olb = P->rlb[i], oub = P->rub[i];
+  P->rtype[i] = type;
+  norm_bounds(type, lb, ub, &P->rlb[i], &P->rub[i]);
+  if (P->valid) mvx::engine_apply_bounds(P, i, type, olb, oub, P->rlb[i], P->rub[i]);
+  P->status = MVX_UNDEF;
+}
+
+void mvx_set_col_bnds(mvx_prob *P, int j, int type, double lb, double ub) {
+  if (j < 1 || j > P->n) fault("set_col_bnds: column out of range");
+  const double olb = P->clb[j], oub = P->cub[j];
+  P->ctype[j] = type;
+  norm_bounds(type, lb, ub, &P->clb[j], &P->cub[j]);
+  if (P->valid) mvx::engine_apply_bounds(P, P->m + j, type, olb, oub, P->clb[j], P->cub[j]);
+  P->status = MVX_UNDEF;
+}
+
+void mvx_set_obj_coef(mvx_prob *P, int j, double coef) {
+  if (j < 0 || j > P->n) fault("set_obj_coef: column out of range");
+  P->c[j] = coef;
+  if (P->valid) mvx::engine_recompute_cost_row(P);
+  P->status = MVX_UNDEF;
+}
+
+void mvx_set_mat_row(mvx_prob *P, int i, int len, const int *ind, const double *val) {
+  if (i < 1 || i > P->m) fault("set_mat_row: row out of range");
+  if (len < 0 || len > P->n) fault("set_mat_row: invalid length");
+  auto row = std::make_shared<std::vector<double>>((size_t)P->n + 1, 0.0);
+  for (int k = 1; k <= len; k++) {
+    if (ind[k] < 1 || ind[k] > P->n) fault("set_mat_row: column index out of range");
+    (*row)[ind[k]] = val[k];
+  }
+  P->A[i] = row;
+  if (P->valid) {
+    if (P->pos[i] <= 0) mvx::engine_invalidate(P); // row of a non-basic auxiliary changed
+    else mvx::engine_row_from_model(P, i);
+  }
+  P->status = MVX_UNDEF;
+}
+
+void mvx_set_col_kind(mvx_prob *P, int j, int kind) {
+  if (j < 1 || j > P->n) fault("set_col_kind: column out of range");
+  if (kind == MVX_BV) {
+    P->kind[j] = MVX_IV;
+    mvx_set_col_bnds(P, j, MVX_DB, 0.0, 1.0);
+  } else if (kind == MVX_CV || kind == MVX_IV) {
+    P->kind[j] = kind;
+  } else
+    fault("set_col_kind: invalid kind");
+}
+
+void mvx_set_col_name(mvx_prob *P, int j, const char *name) {
+  if (j < 1 || j > P->n) fault("set_col_name: column out of range");
+  if (P->cname.size() < (size_t)P->n + 1) P->cname.resize((size_t)P->n + 1);
+  P->cname[j] = name ? name : "";
+}
+
+const char *mvx_get_col_name(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_name: column out of range");
+  if (P->cname.size() < (size_t)P->n + 1 || P->cname[j].empty()) return nullptr;
+  return P->cname[j].c_str();
+}
+
+int mvx_load_dense(mvx_prob *P, int m, int n, const double *A, const double *b, const double *c) {
+  if (m < 1 || n < 1 || !A || !b || !c) return -1;
+  mvx_erase_prob(P);
+  P->dir = MVX_MAX;
+  P->n = n;
+  P->c.assign((size_t)n + 1, 0.0);
+  std::memcpy(&P->c[1], c, (size_t)n * sizeof(double));
+  P->kind.assign((size_t)n + 1, MVX_CV);
+  P->ctype.assign((size_t)n + 1, MVX_LO);
+  P->clb.assign((size_t)n + 1, 0.0);
+  P->cub.assign((size_t)n + 1, INF);
+  P->m = m;
+  P->A.resize((size_t)m + 1);
+  P->rtype.assign((size_t)m + 1, MVX_UP);
+  P->rlb.assign((size_t)m + 1, -INF);
+  P->rub.assign((size_t)m + 1, 0.0);
+  for (int i = 1; i <= m; i++) {
+    auto row = std::make_shared<std::vector<double>>((size_t)n + 1, 0.0);
+    std::memcpy(row->data() + 1, A + (size_t)(i - 1) * n, (size_t)n * sizeof(double));
+    P->A[i] = row;
+    P->rub[i] = b[i - 1];
+  }
+  return 0;
+}
+
+void mvx_init_smcp(mvx_smcp *parm) {
+  parm->msg_lev = 0;
+  parm->meth = 1;
+  parm->it_lim = -1;
+  parm->tol_bnd = 1e-9;
+  parm->tol_dj = 1e-9;
+  parm->tol_piv = 1e-9;
+}
+
+int mvx_simplex(mvx_prob *P, const mvx_smcp *parm) { return mvx::engine_simplex(P, parm); }
+
+int mvx_get_obj_dir(const mvx_prob *P) { return P->dir; }
+int mvx_get_num_rows(const mvx_prob *P) { return P->m; }
+int mvx_get_num_cols(const mvx_prob *P) { return P->n; }
+int mvx_get_num_int(const mvx_prob *P) {
+  int k = 0;
+  for (int j = 1; j <= P->n; j++) k += (P->kind[j] == MVX_IV);
+  return k;
+}
+int mvx_get_status(const mvx_prob *P) { return P->status; }
+
+double mvx_get_obj_val(const mvx_prob *P) {
+  if (!P->valid) return P->c[0];
+  mvx::refresh_solution(P);
+  return P->beta[0];
+}
+double mvx_get_obj_coef(const mvx_prob *P, int j) {
+  if (j < 0 || j > P->n) fault("get_obj_coef: column out of range");
+  return P->c[j];
+}
+
+static double var_prim(const mvx_prob *P, int k) {
+  if (!P->valid) return 0.0;
+  mvx::refresh_solution(P);
+  const int pos = P->pos[k];
+  if (pos > 0) return P->beta[pos];
+  const double lb = (k <= P->m) ? P->rlb[k] : P->clb[k - P->m];
+  const double ub = (k <= P->m) ? P->rub[k] : P->cub[k - P->m];
+  return nb_value(P->nflag[-pos], lb, ub);
+}
+static double var_dual(const mvx_prob *P, int k) {
+  if (!P->valid) return 0.0;
+  mvx::refresh_solution(P);
+  const int pos = P->pos[k];
+  return pos > 0 ? 0.0 : P->dj[-pos];
+}
+static int var_stat(const mvx_prob *P, int k, int type) {
+  if (!P->valid) return (k <= P->m) ? MVX_BS : std_flag(type);
+  const int pos = P->pos[k];
+  return pos > 0 ? MVX_BS : P->nflag[-pos];
+}
+
+double mvx_get_col_prim(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_prim: column out of range");
+  return var_prim(P, P->m + j);
+}
+double mvx_get_row_prim(const mvx_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_prim: row out of range");
+  return var_prim(P, i);
+}
+double mvx_get_col_dual(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_dual: column out of range");
+  return var_dual(P, P->m + j);
+}
+double mvx_get_row_dual(const mvx_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_dual: row out of range");
+  return var_dual(P, i);
+}
+int mvx_get_col_stat(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_stat: column out of range");
+  return var_stat(P, P->m + j, P->ctype[j]);
+}
+int mvx_get_row_stat(const mvx_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_stat: row out of range");
+  return var_stat(P, i, P->rtype[i]);
+}
+int mvx_get_col_kind(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_kind: column out of range");
+  // GLPK reports an integer column with bounds [0,1] as GLP_BV [GLPK-recalled]
+  if (P->kind[j] == MVX_IV && P->ctype[j] == MVX_DB && P->clb[j] == 0.0 && P->cub[j] == 1.0) return MVX_BV;
+  return P->kind[j];
+}
+int mvx_get_row_type(const mvx_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_type: row out of range");
+  return P->rtype[i];
+}
+// absent bounds read back as -/+DBL_MAX [GLPK-recalled]; consumed arithmetically at gmi.cpp:73
+double mvx_get_row_lb(const mvx_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_lb: row out of range");
+  return P->rlb[i] == -INF ? -DBL_MAX : P->rlb[i];
+}
+double mvx_get_row_ub(const mvx_prob *P, int i) {
+  if (i < 1 || i > P->m) fault("get_row_ub: row out of range");
+  return P->rub[i] == INF ? DBL_MAX : P->rub[i];
+}
+int mvx_get_col_type(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_type: column out of range");
+  return P->ctype[j];
+}
+double mvx_get_col_lb(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_lb: column out of range");
+  return P->clb[j] == -INF ? -DBL_MAX : P->clb[j];
+}
+double mvx_get_col_ub(const mvx_prob *P, int j) {
+  if (j < 1 || j > P->n) fault("get_col_ub: column out of range");
+  return P->cub[j] == INF ? DBL_MAX : P->cub[j];
+}
+
+int mvx_get_mat_row(const mvx_prob *P, int i, int *ind, double *val) {
+  // non-zeros in ascending column order (GLPK's own order cannot be observed here)
+  if (i < 1 || i > P->m) fault("get_mat_row: row out of range");
+  const double *a = P->A[i]->data();
+  int len = 0;
+  for (int j = 1; j <= P->n; j++) {
+    if (a[j] != 0.0) {
+      len++;
+      if (ind) ind[len] = j;
+      if (val) val[len] = a[j];
+    }
+  }
+  return len;
+}
+
+int mvx_eval_tab_row(const mvx_prob *P, int k, int *ind, double *val) {
+  if (!P->valid) fault("eval_tab_row: basis does not exist");
+  if (k < 1 || k > P->m + P->n) fault("eval_tab_row: variable out of range");
+  const int pos = P->pos[k];
+  if (pos <= 0) fault("eval_tab_row: variable must be basic");
+  std::vector<double> row((size_t)P->n + 1);
+  if (mvx::engine_get_row(P, pos, row.data()) != 0) fault("eval_tab_row: tableau unavailable");
+  int len = 0;
+  for (int j = 1; j <= P->n; j++) {
+    if (row[j] != 0.0) {
+      len++;
+      ind[len] = P->nvar[j];
+      val[len] = row[j];
+    }
+  }
+  return len;
+}
+
+int mvx_get_it_cnt(const mvx_prob *P) { return P->it_cnt; }
+int mvx_term_out(int flag) {
+  int old = g_term_out;
+  g_term_out = flag;
+  return old;
+}
+const char *mvx_version(void) { return "mvolps-amd 0.1 (gfx950 dense simplex; GLPK-shaped API)"; }
+
+int mvx_get_tableau_ld(const mvx_prob *P) { return P->ld; }
+int mvx_get_tableau(const mvx_prob *P, double *out) { return mvx::engine_get_tableau(P, out); }
+int mvx_get_basis(const mvx_prob *P, int *head, int *nb, int *flag) {
+  if (!P->valid) return -1;
+  head[0] = 0;
+  for (int i = 1; i <= P->m; i++) head[i] = P->bvar[i];
+  nb[0] = 0;
+  flag[0] = 0;
+  for (int j = 1; j <= P->n; j++) {
+    nb[j] = P->nvar[j];
+    flag[j] = P->nflag[j];
+  }
+  return 0;
+}
+
+int mvx_device_count(void) { return mvx::device_count(); }
+int mvx_set_device(int dev) { return mvx::set_device(dev); }
+void mvx_profile_enable(int on) { mvx::profile_enable(on); }
+void mvx_profile_reset(void) { mvx::profile_reset(); }
+double mvx_profile_update_ms(void) { return mvx::profile_update_ms(); }
+long long mvx_profile_update_launches(void) { return mvx::profile_update_launches(); }
+double mvx_last_solve_ms(const mvx_prob *P) { return P->last_ms; }
+void mvx_sync(void) { mvx::sync_stream(); }
+
+} // extern "C"

@@ -1,0 +1,34 @@
+// engine.hpp -- interface between the C ABI layer (capi.cpp) and the device engine.
+#pragma once
+#include "mvx_internal.hpp"
+
+namespace mvx {
+
+int device_count();
+int set_device(int dev);
+void sync_stream();
+
+// solve (glp_simplex)
+int engine_simplex(mvx_prob *P, const mvx_smcp *parm);
+
+// tableau maintenance under model edits; all no-ops while !P->valid
+void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old_ub, double lb, double ub);
+void engine_add_rows(mvx_prob *P, int first, int nrs); // P->m already updated
+void engine_row_from_model(mvx_prob *P, int i);        // row i's auxiliary is basic: rebuild its tableau row
+void engine_recompute_cost_row(mvx_prob *P);
+void engine_invalidate(mvx_prob *P); // drop device state; next solve starts from the slack basis
+
+void engine_copy(mvx_prob *dst, const mvx_prob *src); // device-to-device clone of the slab
+void release_device(mvx_prob *P);
+
+// host mirrors of beta / reduced costs / basis (cheap when already fresh)
+void refresh_solution(const mvx_prob *P);
+int engine_get_tableau(const mvx_prob *P, double *out);
+int engine_get_row(const mvx_prob *P, int row, double *out); // out[0..n]
+
+void profile_enable(int on);
+void profile_reset();
+double profile_update_ms();
+long long profile_update_launches();
+
+} // namespace mvx

@@ -1,0 +1,572 @@
+// kernels.hip -- gfx950 kernels of the dense-simplex engine.
+//
+// Every kernel takes only the device control block (mvx::Ctl), reads its pointers and
+// geometry from there, and returns at once when the solve has already finished
+// (ctl->done), so the host can queue pivots ahead without a round trip per pivot.
+//
+// One simplex pivot = k_select (one 1024-thread workgroup: pricing, ratio test, pivot-row
+// scaling; wave64 shuffle reductions + LDS across the 16 waves) followed by k_update (the
+// HBM-bound Gauss-Jordan rank-1 update streamed over the whole tableau, 16 bytes per lane).
+//
+// Arithmetic is mirrored operation-for-operation by oracle/mvolps_oracle.c; compiled with
+// -ffp-contract=off so fma() appears exactly where written.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "mvx_internal.hpp"
+
+namespace mvx {
+
+#define TIDX ((int)threadIdx.x)
+
+struct Cand {
+  double k1, k2;
+  int idx, aux;
+};
+
+// MODE 0: larger k1, then smaller idx.   MODE 1: smaller k1, then larger k2, then smaller idx.
+template <int MODE>
+__device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b) {
+  if (a.idx == 0) return false;
+  if (b.idx == 0) return true;
+  if (MODE == 0) {
+    if (a.k1 > b.k1) return true;
+    if (a.k1 < b.k1) return false;
+    return a.idx < b.idx;
+  } else {
+    if (a.k1 < b.k1) return true;
+    if (a.k1 > b.k1) return false;
+    if (a.k2 > b.k2) return true;
+    if (a.k2 < b.k2) return false;
+    return a.idx < b.idx;
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Cand o;
+    o.k1 = __shfl_down(c.k1, off, 64);
+    o.k2 = __shfl_down(c.k2, off, 64);
+    o.idx = __shfl_down(c.idx, off, 64);
+    o.aux = __shfl_down(c.aux, off, 64);
+    if (cand_better<MODE>(o, c)) c = o;
+  }
+  return c;
+}
+
+// Block-wide arg-best; result broadcast to every thread.  The key is a strict total order
+// (index included), so the winner does not depend on the reduction tree.
+template <int MODE>
+__device__ Cand block_best(Cand c, Cand *lds) {
+  const int lane = TIDX & 63, wid = TIDX >> 6, nw = (int)blockDim.x >> 6;
+  c = wave_best<MODE>(c);
+  __syncthreads();
+  if (lane == 0) lds[wid] = c;
+  __syncthreads();
+  if (wid == 0) {
+    Cand r = (lane < nw) ? lds[lane] : Cand{0.0, 0.0, 0, 0};
+    r = wave_best<MODE>(r);
+    if (lane == 0) lds[16] = r;
+  }
+  __syncthreads();
+  return lds[16];
+}
+
+__device__ Cand dev_infeas_row(const Ctl *c, Cand *lds) {
+  Cand best{0.0, 0.0, 0, 0};
+  const size_t ld = (size_t)c->ld;
+  const double tol = c->tol_bnd;
+  for (int i = 1 + TIDX; i <= c->m; i += (int)blockDim.x) {
+    const double beta = c->T[(size_t)i * ld];
+    const double lb = c->blb[i], ub = c->bub[i];
+    double viol = 0.0;
+    int up = 0;
+    if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) viol = lb - beta;
+    if (ub < INFINITY && beta > ub + tol * (1.0 + fabs(ub))) {
+      viol = beta - ub;
+      up = 1;
+    }
+    if (viol > 0.0) {
+      Cand x{viol, 0.0, i, up};
+      if (cand_better<0>(x, best)) best = x;
+    }
+  }
+  return block_best<0>(best, lds);
+}
+
+__device__ Cand dev_price(const Ctl *c, const double *cost, double sgn, Cand *lds) {
+  Cand best{0.0, 0.0, 0, 0};
+  const double tol = c->tol_dj;
+  for (int j = 1 + TIDX; j <= c->n; j += (int)blockDim.x) {
+    const int f = c->nflag[j];
+    if (f == MVX_NS) continue;
+    const double dj = sgn * cost[j];
+    const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
+    const bool dn = (f == MVX_NU || f == MVX_NF) && dj < -tol;
+    if (!up && !dn) continue;
+    Cand x{fabs(dj), 0.0, j, up ? 1 : -1};
+    if (cand_better<0>(x, best)) best = x;
+  }
+  return block_best<0>(best, lds);
+}
+
+// Primal ratio test for entering column q moving in direction sdir; also copies the pivot
+// column into colq[0..m].  g (nullable) = phase-1 infeasibility signs.
+__device__ Cand dev_primal_ratio(const Ctl *c, int q, int sdir, const int *g, Cand *lds) {
+  Cand best{0.0, 0.0, 0, 0};
+  const size_t ld = (size_t)c->ld;
+  const double tp = c->tol_piv;
+  for (int i = TIDX; i <= c->m; i += (int)blockDim.x) {
+    const double a = c->T[(size_t)i * ld + q];
+    c->colq[i] = a;
+    if (i == 0) continue;
+    const double aa = (sdir > 0) ? a : -a;
+    const double beta = c->T[(size_t)i * ld];
+    const int gi = g ? g[i] : 0;
+    double t;
+    int up;
+    if (aa > tp) {
+      if (gi < 0) continue;
+      if (gi > 0) {
+        t = (c->blb[i] - beta) / aa;
+        up = 0;
+      } else {
+        const double ub = c->bub[i];
+        if (!(ub < INFINITY)) continue;
+        t = (ub - beta) / aa;
+        up = 1;
+      }
+    } else if (aa < -tp) {
+      if (gi > 0) continue;
+      if (gi < 0) {
+        t = (beta - c->bub[i]) / (-aa);
+        up = 1;
+      } else {
+        const double lb = c->blb[i];
+        if (!(lb > -INFINITY)) continue;
+        t = (beta - lb) / (-aa);
+        up = 0;
+      }
+    } else
+      continue;
+    if (t < 0.0) t = 0.0;
+    Cand x{t, fabs(a), i, up};
+    if (cand_better<1>(x, best)) best = x;
+  }
+  return block_best<1>(best, lds);
+}
+
+__device__ Cand dev_dual_ratio(const Ctl *c, int p, int to_upper, Cand *lds) {
+  Cand best{0.0, 0.0, 0, 0};
+  const double *rowp = c->T + (size_t)p * c->ld;
+  const double *row0 = c->T;
+  const double tp = c->tol_piv, sgn = c->sgn;
+  const bool need_inc = !to_upper;
+  for (int j = 1 + TIDX; j <= c->n; j += (int)blockDim.x) {
+    const int f = c->nflag[j];
+    if (f == MVX_NS) continue;
+    const double a = rowp[j];
+    const double aa = need_inc ? a : -a;
+    const double d = sgn * row0[j];
+    double r;
+    if (aa > tp && (f == MVX_NL || f == MVX_NF)) {
+      r = (f == MVX_NF) ? fabs(d) : (d < 0.0 ? -d : 0.0);
+    } else if (aa < -tp && (f == MVX_NU || f == MVX_NF)) {
+      r = (f == MVX_NF) ? fabs(d) : (d > 0.0 ? d : 0.0);
+    } else
+      continue;
+    const double mag = fabs(a);
+    r = r / mag;
+    Cand x{r, mag, j, 0};
+    if (cand_better<1>(x, best)) best = x;
+  }
+  return block_best<1>(best, lds);
+}
+
+__device__ __forceinline__ double dev_nb_value(int flag, double lb, double ub) {
+  return flag == MVX_NL ? lb : flag == MVX_NU ? ub : flag == MVX_NS ? lb : 0.0;
+}
+__device__ __forceinline__ int dev_leave_flag(double lb, double ub, int to_upper) {
+  if (lb == ub) return MVX_NS;
+  return to_upper ? MVX_NU : MVX_NL;
+}
+
+// Scale the pivot row into srow and publish the pivot description.  All threads call.
+__device__ void dev_prepare_pivot(Ctl *c, int p, int q, int p_up) {
+  const double *rowp = c->T + (size_t)p * c->ld;
+  const double piv = rowp[q];
+  const double bound = p_up ? c->bub[p] : c->blb[p];
+  for (int j = TIDX; j <= c->n; j += (int)blockDim.x) {
+    const double v = rowp[j];
+    c->srow[j] = (j == 0) ? (v - bound) / piv : v / piv;
+  }
+  if (TIDX == 0) {
+    c->step = ST_PIVOT;
+    c->p = p;
+    c->q = q;
+    c->p_up = p_up;
+    c->piv = piv;
+    c->bound = bound;
+    c->xq = dev_nb_value(c->nflag[q], c->nlb[q], c->nub[q]);
+    c->leave_flag = dev_leave_flag(c->blb[p], c->bub[p], p_up);
+  }
+}
+
+// Entering column chosen: ratio test, then bound flip (done here) or pivot preparation.
+// Returns false when no row blocks (unbounded ray).
+__device__ bool dev_primal_step(Ctl *c, int q, int sdir, const int *g, Cand *lds) {
+  Cand r = dev_primal_ratio(c, q, sdir, g, lds);
+  const double lbq = c->nlb[q], ubq = c->nub[q];
+  const int fq = c->nflag[q];
+  if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+    const double tf = ubq - lbq;
+    if (r.idx == 0 || tf <= r.k1) {
+      const double delta = (sdir > 0) ? tf : -tf;
+      __syncthreads(); // colq complete
+      const size_t ld = (size_t)c->ld;
+      for (int i = TIDX; i <= c->m; i += (int)blockDim.x)
+        c->T[(size_t)i * ld] = fma(c->colq[i], delta, c->T[(size_t)i * ld]);
+      if (TIDX == 0) {
+        c->nflag[q] = (sdir > 0) ? MVX_NU : MVX_NL;
+        c->step = ST_FLIP;
+        c->n_flips++;
+      }
+      return true;
+    }
+  }
+  if (r.idx == 0) return false;
+  dev_prepare_pivot(c, r.idx, q, r.aux);
+  return true;
+}
+
+__device__ __forceinline__ void dev_finish(Ctl *c, int code, int phase, int rounds) {
+  if (TIDX == 0) {
+    c->done = code;
+    c->phase = phase;
+    c->rounds = rounds;
+    c->step = ST_NONE;
+  }
+}
+
+// ---------------------------------------------------------------------------- k_select
+// Device-side restatement of orc_simplex's round loop + one pricing / ratio-test step.
+__global__ __launch_bounds__(1024) void k_select(Ctl *c) {
+  __shared__ Cand lds[17];
+  if (c->done != D_RUN) return;
+  int phase = c->phase, rounds = c->rounds;
+  int p = 0, p_up = 0, q = 0, sdir = 0, kind = 0; // kind 1 primal, 2 dual
+  for (;;) {
+    if (phase == PH_START) {
+      Cand r = dev_infeas_row(c, lds);
+      if (r.idx == 0) {
+        phase = PH_PRIMAL2;
+      } else {
+        Cand pr = dev_price(c, c->T, c->sgn, lds);
+        if (pr.idx != 0) {
+          dev_finish(c, D_NEED_PHASE1, PH_PHASE1, rounds);
+          return;
+        }
+        phase = PH_DUAL;
+        p = r.idx;
+        p_up = r.aux;
+        kind = 2;
+        break;
+      }
+    }
+    if (phase == PH_PRIMAL2) {
+      Cand pr = dev_price(c, c->T, c->sgn, lds);
+      if (pr.idx != 0) {
+        q = pr.idx;
+        sdir = pr.aux;
+        kind = 1;
+        break;
+      }
+      Cand r = dev_infeas_row(c, lds);
+      if (r.idx == 0) {
+        dev_finish(c, D_OPT, phase, rounds);
+        return;
+      }
+      if (++rounds >= 64) {
+        dev_finish(c, D_FAIL, phase, rounds);
+        return;
+      }
+      phase = PH_DUAL;
+      p = r.idx;
+      p_up = r.aux;
+      kind = 2;
+      break;
+    }
+    if (phase == PH_DUAL) {
+      Cand r = dev_infeas_row(c, lds);
+      if (r.idx != 0) {
+        p = r.idx;
+        p_up = r.aux;
+        kind = 2;
+        break;
+      }
+      if (++rounds >= 64) {
+        dev_finish(c, D_FAIL, phase, rounds);
+        return;
+      }
+      phase = PH_PRIMAL2;
+    }
+  }
+  if (c->budget == 0) {
+    dev_finish(c, D_ITLIM, phase, rounds);
+    return;
+  }
+  if (kind == 1) {
+    if (!dev_primal_step(c, q, sdir, nullptr, lds)) {
+      dev_finish(c, D_UNBND, phase, rounds);
+      return;
+    }
+  } else {
+    Cand dr = dev_dual_ratio(c, p, p_up, lds);
+    if (dr.idx == 0) {
+      dev_finish(c, D_NOFEAS, phase, rounds);
+      return;
+    }
+    q = dr.idx;
+    const size_t ld = (size_t)c->ld;
+    for (int i = TIDX; i <= c->m; i += (int)blockDim.x) c->colq[i] = c->T[(size_t)i * ld + q];
+    dev_prepare_pivot(c, p, q, p_up);
+  }
+  if (TIDX == 0) {
+    c->phase = phase;
+    c->rounds = rounds;
+  }
+}
+
+// ------------------------------------------------------------------------ phase-1 kernels
+__global__ __launch_bounds__(1024) void k_p1_head(Ctl *c) {
+  __shared__ int s_cnt[16];
+  if (c->done != D_RUN) return;
+  const size_t ld = (size_t)c->ld;
+  const double tol = c->tol_bnd;
+  int cnt = 0;
+  for (int i = 1 + TIDX; i <= c->m; i += (int)blockDim.x) {
+    const double beta = c->T[(size_t)i * ld];
+    const double lb = c->blb[i], ub = c->bub[i];
+    int g = 0;
+    if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) g = 1;
+    if (ub < INFINITY && beta > ub + tol * (1.0 + fabs(ub))) g = -1;
+    c->gflag[i] = g;
+    c->wts[i] = (double)g;
+    cnt += (g != 0);
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if ((TIDX & 63) == 0) s_cnt[TIDX >> 6] = cnt;
+  __syncthreads();
+  if (TIDX == 0) {
+    int tot = 0;
+    for (int w = 0; w < ((int)blockDim.x >> 6); w++) tot += s_cnt[w];
+    if (tot == 0) {
+      c->done = D_PFEAS;
+      c->step = ST_NONE;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
+  __shared__ Cand lds[17];
+  if (c->done != D_RUN) return;
+  Cand pr = dev_price(c, c->cost1, 1.0, lds);
+  if (pr.idx == 0) {
+    dev_finish(c, D_NOFEAS, PH_PHASE1, c->rounds);
+    return;
+  }
+  if (c->budget == 0) {
+    dev_finish(c, D_ITLIM, PH_PHASE1, c->rounds);
+    return;
+  }
+  if (!dev_primal_step(c, pr.idx, pr.aux, c->gflag, lds)) dev_finish(c, D_FAIL, PH_PHASE1, c->rounds);
+}
+
+// ---------------------------------------------------------------------------- k_update
+// Gauss-Jordan rank-1 update, streamed: every tableau entry read once and written once.
+//   T[i][j] = fma(-colq[i], srow[j], T[i][j])   (i != p, j != q)
+//   T[i][q] = colq[i] / piv                      (i != p)
+//   T[p][j] = -srow[j], T[p][q] = 1/piv, T[p][0] = xq - srow[0]
+// Block = 256 lanes x 2 columns (16 B per lane, 4 KB per row segment), TR rows deep.
+template <int TR>
+__global__ __launch_bounds__(256) void k_update(Ctl *c) {
+  if (c->done != D_RUN || c->step != ST_PIVOT) return;
+  const int m = c->m, n = c->n, p = c->p, q = c->q;
+  const size_t ld = (size_t)c->ld;
+  const double piv = c->piv;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && TIDX == 0) {
+    // basis bookkeeping: entering variable takes row p, leaving variable takes column q
+    const int kv = c->bvar[p];
+    const double klb = c->blb[p], kub = c->bub[p];
+    c->bvar[p] = c->nvar[q];
+    c->blb[p] = c->nlb[q];
+    c->bub[p] = c->nub[q];
+    c->nvar[q] = kv;
+    c->nlb[q] = klb;
+    c->nub[q] = kub;
+    c->nflag[q] = c->leave_flag;
+    c->it_cnt++;
+    if (c->budget > 0) c->budget--;
+  }
+  const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
+  if (j0 > n) return;
+  const double2 s = *reinterpret_cast<const double2 *>(c->srow + j0);
+  const bool q0 = (j0 == q), q1 = (j0 + 1 == q);
+  const int i0 = (int)blockIdx.y * TR;
+  double *base = c->T + (size_t)i0 * ld + j0;
+  const double *colq = c->colq + i0;
+#pragma unroll
+  for (int r = 0; r < TR; r++) {
+    const int i = i0 + r;
+    if (i > m) break;
+    double2 *ptr = reinterpret_cast<double2 *>(base + (size_t)r * ld);
+    double2 v = *ptr;
+    const double ci = colq[r];
+    if (i == p) {
+      v.x = -s.x;
+      v.y = -s.y;
+      if (q0) v.x = 1.0 / piv;
+      if (q1) v.y = 1.0 / piv;
+      if (j0 == 0) v.x = c->xq - s.x;
+    } else {
+      v.x = fma(-ci, s.x, v.x);
+      v.y = fma(-ci, s.y, v.y);
+      if (q0) v.x = ci / piv;
+      if (q1) v.y = ci / piv;
+    }
+    *ptr = v;
+  }
+}
+
+// ---------------------------------------------------------------------------- k_rowcomb
+// out[j] = base[j] + sum over 64-row chunks (in order) of fma-chain sum_i w[i]*T[i][j].
+__global__ __launch_bounds__(256) void k_rowcomb_partial(Ctl *c, int respect_done) {
+  if (respect_done && c->done != D_RUN) return;
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  if (j > c->n) return;
+  const int chunk = (int)blockIdx.y;
+  const int i0 = 1 + chunk * ROWCOMB_CHUNK;
+  int i1 = i0 + ROWCOMB_CHUNK - 1;
+  if (i1 > c->m) i1 = c->m;
+  const size_t ld = (size_t)c->ld;
+  double acc = 0.0;
+  for (int i = i0; i <= i1; i++) {
+    const double w = c->wts[i];
+    if (w != 0.0) acc = fma(w, c->T[(size_t)i * ld + j], acc);
+  }
+  c->part[(size_t)chunk * ld + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_rowcomb_final(Ctl *c, int respect_done, int nchunks) {
+  if (respect_done && c->done != D_RUN) return;
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  if (j > c->n) return;
+  const size_t ld = (size_t)c->ld;
+  double out = c->rc_base ? c->rc_base[j] : 0.0;
+  for (int ch = 0; ch < nchunks; ch++) out = out + c->part[(size_t)ch * ld + j];
+  c->rc_out[j] = out;
+}
+
+// beta += T[:, jj] * delta  (a non-basic variable moved by delta)
+__global__ __launch_bounds__(256) void k_shift_nonbasic(double *T, int ld, int m, int jj, double delta) {
+  const int i = (int)blockIdx.x * 256 + TIDX;
+  if (i > m) return;
+  double *row = T + (size_t)i * ld;
+  row[0] = fma(row[jj], delta, row[0]);
+}
+
+__global__ __launch_bounds__(64) void k_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub) {
+  if (TIDX == 0) {
+    blb[i] = lb;
+    bub[i] = ub;
+  }
+}
+__global__ __launch_bounds__(64) void k_set_nonbasic(double *nlb, double *nub, int *nflag, int j, double lb, double ub, int flag) {
+  if (TIDX == 0) {
+    nlb[j] = lb;
+    nub[j] = ub;
+    nflag[j] = flag;
+  }
+}
+
+// new empty rows first..last: zero body, basic auxiliary first.., free bounds; shift the
+// structural variable numbers by nrs
+__global__ __launch_bounds__(256) void k_add_rows(double *T, int ld, int n, int *bvar, double *blb, double *bub, int *nvar,
+                                                  int first, int nrs) {
+  const int t = (int)blockIdx.x * 256 + TIDX;
+  for (int r = 0; r < nrs; r++) {
+    if (t <= n) T[(size_t)(first + r) * ld + t] = 0.0;
+  }
+  if (t < nrs) {
+    bvar[first + t] = first + t;
+    blb[first + t] = -INFINITY;
+    bub[first + t] = INFINITY;
+  }
+  if (t >= 1 && t < first && bvar[t] >= first) bvar[t] += nrs;
+  if (t >= 1 && t <= n && nvar[t] >= first) nvar[t] += nrs;
+}
+
+// ---------------------------------------------------------------------------- k_export
+// Pack what the host needs after a solve into one staging buffer:
+//   [Ctl][beta (m_cap+1) f64][d (ld) f64][bvar (m_cap+1) i32][nvar (ld) i32][nflag (ld) i32]
+__global__ __launch_bounds__(256) void k_export(Ctl *c, unsigned char *stage, int force) {
+  const int t = (int)blockIdx.x * 256 + TIDX;
+  if (t == 0) *reinterpret_cast<Ctl *>(stage) = *c;
+  if (!force && c->done == D_RUN) return;
+  const int m = c->m, n = c->n, ld = c->ld, mc = c->m_cap;
+  double *beta = reinterpret_cast<double *>(stage + sizeof(Ctl));
+  double *dj = beta + (mc + 1);
+  int *bv = reinterpret_cast<int *>(dj + ld);
+  int *nv = bv + (mc + 1);
+  int *nf = nv + ld;
+  if (t <= m) {
+    beta[t] = c->T[(size_t)t * ld];
+    bv[t] = c->bvar[t];
+  }
+  if (t <= n) {
+    dj[t] = c->T[t];
+    nv[t] = c->nvar[t];
+    nf[t] = c->nflag[t];
+  }
+}
+
+// ------------------------------------------------------------------ launch wrappers
+constexpr int UPDATE_TR = 16;
+
+void launch_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, s, d_ctl); }
+void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s) {
+  const int pairs = (n + 2) / 2;
+  dim3 grid((pairs + 255) / 256, (m + 1 + UPDATE_TR - 1) / UPDATE_TR);
+  hipLaunchKernelGGL(k_update<UPDATE_TR>, grid, dim3(256), 0, s, d_ctl);
+}
+void launch_p1_head(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_head, dim3(1), dim3(1024), 0, s, d_ctl); }
+void launch_p1_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_select, dim3(1), dim3(1024), 0, s, d_ctl); }
+void launch_rowcomb(Ctl *d_ctl, int m, int n, int respect_done, hipStream_t s) {
+  const int nchunks = (m + ROWCOMB_CHUNK - 1) / ROWCOMB_CHUNK;
+  dim3 grid((n + 1 + 255) / 256, nchunks > 0 ? nchunks : 1);
+  hipLaunchKernelGGL(k_rowcomb_partial, grid, dim3(256), 0, s, d_ctl, respect_done);
+  hipLaunchKernelGGL(k_rowcomb_final, dim3((n + 1 + 255) / 256), dim3(256), 0, s, d_ctl, respect_done, nchunks);
+}
+void launch_shift_nonbasic(double *T, int ld, int m, int jj, double delta, hipStream_t s) {
+  hipLaunchKernelGGL(k_shift_nonbasic, dim3((m + 1 + 255) / 256), dim3(256), 0, s, T, ld, m, jj, delta);
+}
+void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_basic_bounds, dim3(1), dim3(64), 0, s, blb, bub, i, lb, ub);
+}
+void launch_set_nonbasic(double *nlb, double *nub, int *nflag, int j, double lb, double ub, int flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_nonbasic, dim3(1), dim3(64), 0, s, nlb, nub, nflag, j, lb, ub, flag);
+}
+void launch_add_rows(double *T, int ld, int n, int *bvar, double *blb, double *bub, int *nvar, int first, int nrs, int m_new,
+                     hipStream_t s) {
+  int span = (n > m_new ? n : m_new) + 1;
+  hipLaunchKernelGGL(k_add_rows, dim3((span + 255) / 256), dim3(256), 0, s, T, ld, n, bvar, blb, bub, nvar, first, nrs);
+}
+void launch_export(Ctl *d_ctl, unsigned char *stage, int m, int n, int force, hipStream_t s) {
+  int span = (n > m ? n : m) + 1;
+  hipLaunchKernelGGL(k_export, dim3((span + 255) / 256), dim3(256), 0, s, d_ctl, stage, force);
+}
+
+} // namespace mvx

@@ -1,0 +1,96 @@
+// mvx_internal.hpp -- host-side model + device control block of the MI355X LP engine.
+//
+// Layout in HBM (one slab per problem handle, see DESIGN.md "Data layout"):
+//   T      (m_cap+1) x ld doubles, row-major, ld a multiple of 32 doubles (256 B rows)
+//          T[0][0] objective, T[0][j] reduced costs, T[i][0] basic values, T[i][j] body
+//   bvar/blb/bub   per tableau row   (basic variable, its bounds)
+//   nvar/nflag/nlb/nub per tableau column (non-basic variable, status, bounds)
+// Everything position-indexed so that every kernel access is contiguous.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mvx.h"
+
+namespace mvx {
+
+constexpr int ROWCOMB_CHUNK = 64; // rows per partial sum of k_rowcomb (fixed summation order)
+constexpr int LD_ALIGN = 32;      // doubles; 256-byte rows
+constexpr int ROW_SLACK = 64;     // spare tableau rows per handle for cut appends (cut.cpp:23)
+
+// state-machine phases (device-driven; mirrors orc_simplex's round loop)
+enum : int { PH_START = 0, PH_PRIMAL2 = 1, PH_DUAL = 2, PH_PHASE1 = 3 };
+// done codes
+enum : int { D_RUN = 0, D_OPT = 1, D_UNBND = 2, D_NOFEAS = 3, D_ITLIM = 4, D_PFEAS = 5, D_FAIL = 6, D_NEED_PHASE1 = 7 };
+// step kinds
+enum : int { ST_NONE = 0, ST_PIVOT = 1, ST_FLIP = 2 };
+
+// Device-resident control block.  Kernels take only a pointer to it, so one launch
+// sequence (and one captured hipGraph) serves every problem handle.
+struct Ctl {
+  // geometry + pointers (written by the host before a solve)
+  double *T;
+  int *bvar; double *blb; double *bub;
+  int *nvar; int *nflag; double *nlb; double *nub;
+  double *colq;   // [m_cap+1] copy of the pivot column (old values)
+  double *srow;   // [ld]      pivot row / pivot
+  double *cost1;  // [ld]      phase-1 cost row
+  double *wts;    // [m_cap+1] row weights for k_rowcomb
+  int *gflag;     // [m_cap+1] phase-1 infeasibility signs
+  double *part;   // [nchunks x ld] partial sums of k_rowcomb
+  double *rc_base; // [ld] base vector for k_rowcomb (nullable)
+  double *rc_out;  // destination of k_rowcomb
+  int m, n, ld, m_cap;
+  // parameters
+  double sgn, tol_bnd, tol_dj, tol_piv;
+  // running state
+  int phase, done, rounds, budget;
+  int it_cnt, n_flips;
+  int step, p, q, sdir, p_up, leave_flag;
+  double piv, bound, xq, delta;
+  int pad_[2];
+};
+
+struct HostModel; // forward
+
+// shared immutable matrix row (1-based, n+1 doubles)
+using RowPtr = std::shared_ptr<std::vector<double>>;
+
+} // namespace mvx
+
+struct mvx_prob {
+  // ---- model (host) ----
+  int m = 0, n = 0;
+  int dir = MVX_MIN;
+  std::vector<mvx::RowPtr> A; // A[i], i=1..m; rows shared between clones (copy-on-write)
+  std::vector<double> c;      // c[0..n]
+  std::vector<int> kind;      // kind[1..n]
+  std::vector<std::string> cname;
+  std::vector<int> rtype;
+  std::vector<double> rlb, rub; // normalised (+-inf when absent)
+  std::vector<int> ctype;
+  std::vector<double> clb, cub;
+  // ---- engine state ----
+  bool valid = false;   // device tableau + basis exist
+  int status = MVX_UNDEF;
+  int it_cnt = 0;
+  double last_ms = 0.0;
+  // host mirrors of the basis (always in sync while valid)
+  std::vector<int> bvar, nvar, nflag; // [m+1], [n+1], [n+1]
+  std::vector<int> pos;               // pos[k], k=1..m+n: +row or -column
+  // cached solution vectors (refreshed by export after each solve / modification)
+  mutable bool sol_fresh = false;
+  mutable std::vector<double> beta; // [m+1], beta[0] = objective
+  mutable std::vector<double> dj;   // [n+1]
+  // ---- device slab ----
+  void *slab = nullptr;
+  size_t slab_bytes = 0;
+  int m_cap = 0, ld = 0;
+  double *d_T = nullptr;
+  int *d_bvar = nullptr; double *d_blb = nullptr; double *d_bub = nullptr;
+  int *d_nvar = nullptr; int *d_nflag = nullptr; double *d_nlb = nullptr; double *d_nub = nullptr;
+};

@@ -1,0 +1,52 @@
+"""Shared random-LP builders for the tests (seeded, small)."""
+import numpy as np
+
+from mvolps_amd.capi import DB, FR, FX, LO, MAX, MIN, UP
+
+
+def random_general_lp(rng, mmax=9, nmax=10):
+    """Feasible-by-construction LP with every bound type on rows and columns."""
+    m = int(rng.integers(2, mmax))
+    n = int(rng.integers(2, nmax))
+    A = np.round(rng.normal(size=(m, n)) * 3)
+    A[rng.random((m, n)) < 0.3] = 0
+    x0 = rng.integers(0, 4, size=n).astype(float)
+    act = A @ x0
+    row_b, col_b = [], []
+    for i in range(m):
+        t = int(rng.choice([LO, UP, DB, FX, FR], p=[0.25, 0.35, 0.2, 0.1, 0.1]))
+        l = act[i] - rng.integers(0, 3)
+        u = act[i] + rng.integers(0, 3)
+        if t == FX:
+            l = u = act[i]
+        if t == DB and l == u:
+            u = l + 1
+        row_b.append((t, float(l), float(u)))
+    for j in range(n):
+        t = int(rng.choice([LO, UP, DB, FX, FR], p=[0.4, 0.1, 0.35, 0.05, 0.1]))
+        l = x0[j] - rng.integers(0, 3)
+        u = x0[j] + rng.integers(0, 4)
+        if t == FX:
+            l = u = x0[j]
+        if t == DB and l == u:
+            u = l + 1
+        col_b.append((t, float(l), float(u)))
+    c = np.round(rng.normal(size=n) * 5)
+    direction = int(rng.choice([MIN, MAX]))
+    return A, row_b, col_b, c, direction
+
+
+def bounds_arrays(bnds):
+    lo = np.array([l if t in (LO, DB, FX) else -np.inf for t, l, u in bnds])
+    hi = np.array([u if t in (UP, DB) else (l if t == FX else np.inf) for t, l, u in bnds])
+    return lo, hi
+
+
+def load_ilp(api, A, b, c, U):
+    from mvolps_amd.capi import IV
+
+    m, n = A.shape
+    P = api.create()
+    colb = [(DB, 0.0, U) if np.isfinite(U) else (LO, 0.0, 0.0)] * n
+    P.load_general(A, [(UP, 0.0, float(bi)) for bi in b], colb, c, kinds=[IV] * n, direction=MAX)
+    return P

@@ -1,0 +1,184 @@
+"""GPU parity: the HIP engine against the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): basis indices and statuses bit-exact; tableau entries and
+objective are compared BITWISE as well (np.array_equal), which is stronger than the 1e-9
+relative tolerance asked for -- both sides run the same fma/div sequence.
+"""
+import numpy as np
+import pytest
+
+from mvolps_amd import capi, synth
+from mvolps_amd.capi import DB, LO, MAX, UP
+
+from . import lpgen
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same_state(g, o, what=""):
+    assert g.status == o.status, (what, g.status, o.status)
+    assert g.it_cnt == o.it_cnt, (what, g.it_cnt, o.it_cnt)
+    hg, ho = g.basis(), o.basis()
+    for x, y, nm in zip(hg, ho, ("head", "nonbasic", "flag")):
+        assert np.array_equal(x, y), (what, nm)
+    tg, to = g.tableau(), o.tableau()
+    assert np.array_equal(tg, to), (what, "tableau max abs diff %g" % np.nanmax(np.abs(tg - to)))
+    assert g.obj == o.obj
+    assert np.array_equal(g.col_prim(), o.col_prim())
+    assert np.array_equal(g.row_prim(), o.row_prim())
+    assert np.array_equal(g.col_stat(), o.col_stat())
+    assert np.array_equal(g.row_stat(), o.row_stat())
+
+
+@pytest.mark.parametrize("m,n,seed", [(3, 5, 1), (17, 33, 2), (64, 128, 12345), (128, 256, 12345), (100, 37, 5), (256, 512, 12345)])
+def test_dense_lp_bit_exact(gpu, orc, m, n, seed):
+    A, b, c = synth.dense_lp(m, n, seed)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+        assert P.simplex() == 0
+    assert g.status == capi.OPT
+    assert_same_state(g, o, "dense %dx%d" % (m, n))
+
+
+def test_iteration_limit_then_resume(gpu, orc):
+    A, b, c = synth.dense_lp(128, 256, 7)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+        assert P.simplex(it_lim=10) == capi.EITLIM
+    assert g.it_cnt == 10
+    assert_same_state(g, o, "after 10 pivots")
+    for P in (g, o):
+        assert P.simplex() == 0
+    assert_same_state(g, o, "resumed")
+
+
+def test_general_bounds_bit_exact(gpu, orc):
+    """All bound types, both directions: exercises phase 1, the dual simplex and bound flips."""
+    rng = np.random.default_rng(7)
+    seen = set()
+    for trial in range(120):
+        A, row_b, col_b, c, direction = lpgen.random_general_lp(rng)
+        g, o = gpu.create(), orc.create()
+        for P in (g, o):
+            P.load_general(A, row_b, col_b, c, c0=1.5, direction=direction)
+            P.rc = P.simplex()
+        assert g.rc == o.rc, trial
+        assert_same_state(g, o, "general trial %d" % trial)
+        seen.add(g.status)
+    assert capi.OPT in seen and len(seen) >= 2
+
+
+def test_branch_children_warm_start(gpu, orc):
+    """bs.cpp:269-288: clone the solved node twice, change one column bound, re-solve."""
+    A, b, c, U = synth.dense_ilp(24, 48, seed=6, U=2)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    assert_same_state(g, o, "root")
+    x = o.col_prim()
+    frac = [j + 1 for j in range(len(x)) if np.trunc(x[j]) != x[j]]
+    assert frac
+    pick = frac[0]
+    for P in (g, o):
+        P.s2, P.s3 = P.copy(), P.copy()
+        P.api.set_col_bnds(P.s2.h, pick, UP, 0.0, float(np.floor(x[pick - 1])))
+        P.api.set_col_bnds(P.s3.h, pick, LO, float(np.ceil(x[pick - 1])), 0.0)
+        P.s2.simplex()
+        P.s3.simplex()
+    assert_same_state(g.s2, o.s2, "S2")
+    assert_same_state(g.s3, o.s3, "S3")
+    # the parent is untouched by its children
+    assert_same_state(g, o, "parent after children")
+    # re-solve of an optimal clone costs zero pivots (bs.cpp:116-117)
+    for P in (g, o):
+        P.again = P.s2.copy(names=capi.OFF)
+        P.again.simplex()
+    assert g.again.it_cnt == g.s2.it_cnt
+    assert_same_state(g.again, o.again, "re-solve")
+
+
+def test_cut_row_append(gpu, orc):
+    """cut.cpp:23-43: add one >= row to a solved problem, then warm-start children from it."""
+    A, b, c, U = synth.dense_ilp(16, 32, seed=5, U=2)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    x = o.col_prim()
+    n = len(x)
+    rng = np.random.default_rng(3)
+    v = np.round(rng.normal(size=n) * 2)
+    ind = np.arange(n + 1, dtype=np.int32)
+    val = np.concatenate([[0.0], v])
+    lb = float(v @ x) + 0.75  # violated by the current vertex
+    for P in (g, o):
+        r = P.api.add_rows(P.h, 1)
+        assert r == 17
+        P.set_mat_row(r, ind, val)
+        P.api.set_row_bnds(P.h, r, LO, lb, 0.0)
+    assert np.array_equal(g.tableau(), o.tableau())
+    assert np.array_equal(g.row_prim(), o.row_prim())
+    for P in (g, o):
+        P.ch = P.copy()
+        P.ch.simplex()
+    assert_same_state(g.ch, o.ch, "after cut")
+
+
+def test_objective_change_recomputes_cost_row(gpu, orc):
+    A, b, c = synth.dense_lp(40, 70, 11)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+        P.simplex()
+        P.api.set_obj_coef(P.h, 3, 2.5)
+        P.api.set_obj_coef(P.h, 0, -1.0)
+    assert np.array_equal(g.tableau(), o.tableau())
+    for P in (g, o):
+        P.simplex()
+    assert_same_state(g, o, "after objective change")
+
+
+def test_eval_tab_row_and_queries(gpu, orc):
+    A, b, c, U = synth.dense_ilp(12, 20, seed=4, U=3)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        P.simplex()
+    m = g.m
+    stat = o.col_stat()
+    for j in range(1, g.n + 1):
+        if stat[j - 1] == capi.BS:
+            ig, vg = g.eval_tab_row(m + j)
+            io, vo = o.eval_tab_row(m + j)
+            assert np.array_equal(ig, io) and np.array_equal(vg, vo)
+    for i in range(1, m + 1):
+        assert g.api.get_row_ub(g.h, i) == o.api.get_row_ub(o.h, i)
+        ig, vg = g.get_mat_row(i)
+        io, vo = o.get_mat_row(i)
+        assert np.array_equal(ig, io) and np.array_equal(vg, vo)
+    for j in range(1, g.n + 1):
+        assert g.api.get_col_kind(g.h, j) == o.api.get_col_kind(o.h, j)
+        assert g.api.get_col_ub(g.h, j) == o.api.get_col_ub(o.h, j)
+        assert g.api.get_col_dual(g.h, j) == o.api.get_col_dual(o.h, j)
+
+
+def test_infeasible_and_unbounded(gpu, orc):
+    # infeasible: x1 + x2 <= 1, x1 + x2 >= 3
+    A = np.array([[1.0, 1.0], [1.0, 1.0]])
+    rows = [(UP, 0.0, 1.0), (LO, 3.0, 0.0)]
+    cols = [(LO, 0.0, 0.0)] * 2
+    for api in (gpu, orc):
+        P = api.create()
+        P.load_general(A, rows, cols, np.array([1.0, 1.0]), direction=MAX)
+        P.simplex()
+        assert P.status == capi.NOFEAS
+    # unbounded: max x1, x1 - x2 <= 1
+    A = np.array([[1.0, -1.0]])
+    for api in (gpu, orc):
+        P = api.create()
+        P.load_general(A, [(UP, 0.0, 1.0)], cols, np.array([1.0, 0.0]), direction=MAX)
+        P.simplex()
+        assert P.status == capi.UNBND
