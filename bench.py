@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- simplex pivots/s on a dense fp64 tableau, with the HBM roofline of the rank-1
+update kernel and a same-host CPU baseline (BASELINE.json metric).
+
+One "step" = one simplex pivot (k_select + the streamed Gauss-Jordan rank-1 update k_update)
+on the synthetic dense LP of BASELINE.md config 4: m=4096, n=8192, fp64, splitmix64 seed
+12345 (+rank).  The tableau is resident in HBM before the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: every rank solves its own LP of the same shape (seed 12345 + rank) -- independent
+subproblems, no data-path collective (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (spec 8.0 TB/s)
+
+
+def bytes_per_pivot(m, n):
+    """Algorithmic bytes of one rank-1 update: every tableau entry read once + written once (fp64)."""
+    return 16 * (m + 1) * (n + 1)
+
+
+def cpu_baseline(m, n, seed, budget_s=12.0, max_pivots=400):
+    """Oracle (CPU restatement, OpenMP row-parallel update) on a bounded sample of the same LP."""
+    threads = min(os.cpu_count() or 1, 16)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = int(os.environ["OMP_NUM_THREADS"])
+    from mvolps_amd import synth
+    from oracle import oracle
+
+    A, b, c = synth.dense_lp(m, n, seed)
+    P = oracle.api().create()
+    P.load_dense(A, b, c)
+    P.simplex(it_lim=2)  # builds the tableau + touches the pages
+    piv0 = P.it_cnt
+    t0 = time.perf_counter()
+    while True:
+        P.simplex(it_lim=20)
+        el = time.perf_counter() - t0
+        if el >= budget_s or P.it_cnt - piv0 >= max_pivots or P.status == 5:
+            break
+    done = P.it_cnt - piv0
+    return {
+        "value": done / el,
+        "unit": "pivots/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "first %d pivots of the same %dx%d LP (seed %d), oracle/mvolps_oracle.c, %d OpenMP threads"
+        % (done, m, n, seed, threads),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=100, help="extra pivots timed per-kernel with HIP events")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    import mvolps_amd
+
+    mvolps_amd.require_device()
+    api = mvolps_amd.api()
+    if api.set_device(local_rank) != 0:
+        raise SystemExit("cannot bind device %d" % local_rank)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from mvolps_amd import synth
+
+    m, n = args.m, args.n
+    A, b, c = synth.dense_lp(m, n, args.seed + rank)
+    P = api.create()
+    P.load_dense(A, b, c)
+    del A
+    # warmup: builds the tableau in HBM and runs W untimed pivots
+    rc = P.simplex(it_lim=args.warmup)
+    piv_w = P.it_cnt
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    rc = P.simplex(it_lim=args.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    steps_done = P.it_cnt - piv_w
+    if steps_done != args.steps:
+        raise SystemExit("rank %d: LP reached status %d after %d of %d timed pivots -- pick fewer steps" % (rank, P.status, steps_done, args.steps))
+    device_ms = api.last_solve_ms(P.h)
+
+    # max over ranks
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el_max = float(t.item())
+
+    # per-kernel pass: HIP events around every k_update launch, on the engine's own stream
+    roof = None
+    if rank == 0:
+        api.profile_reset()
+        api.profile_enable(1)
+        P.simplex(it_lim=args.profile_steps)
+        api.profile_enable(0)
+        # events were recorded around every queued launch; only launches that pivoted moved data,
+        # the queued-ahead no-op launches after the limit are a few microseconds each
+        k_ms = api.profile_update_ms()
+        k_n = api.profile_update_launches()
+        pivots = P.it_cnt - piv_w - steps_done
+        if pivots > 0 and k_ms > 0:
+            avg_ms = k_ms / pivots
+            achieved = bytes_per_pivot(m, n) / (avg_ms * 1e-3) / 1e9
+            roof = {
+                "bound": "hbm",
+                "kernel": "k_update",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_us": avg_ms * 1e3,
+                "launches_timed": pivots,
+                "bytes_per_launch": bytes_per_pivot(m, n),
+            }
+
+    out = None
+    if rank == 0:
+        value = world * args.steps / el_max
+        out = {
+            "metric": "simplex_pivots_per_s",
+            "value": value,
+            "unit": "pivots/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "dense LP m=%d n=%d fp64, splitmix64 seed %d+rank, primal simplex pivots on the (m+1)x(n+1) tableau" % (m, n, args.seed),
+                "m": m,
+                "n": n,
+                "bytes_per_pivot": bytes_per_pivot(m, n),
+                "parallelism": "independent LP per GPU (x%d)" % world,
+            },
+            "pivot_roofline_frac": (args.steps / el_max) * bytes_per_pivot(m, n) / 1e9 / HBM_PEAK_GBS,
+            "device_ms_per_step": device_ms / args.steps,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(m, n, args.seed)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -452,15 +452,21 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
   const int m = P->m, n = P->n;
   int batch = 8;
   int done = D_RUN;
+  int seen_steps = 0; // pivots + flips already accounted to the profile
+  int seen_pivots = 0;
   Ctl snap;
   for (;;) {
     size_t ev_used = 0;
-    if (c.prof && c.ev_pool.size() < (size_t)2 * batch) {
+    if (c.prof && c.ev_pool.size() < (size_t)2 * batch) { // sized for the largest batch
       size_t old = c.ev_pool.size();
       c.ev_pool.resize((size_t)2 * batch);
       for (size_t k = old; k < c.ev_pool.size(); k++) HIPCHECK(hipEventCreate(&c.ev_pool[k]));
     }
-    for (int k = 0; k < batch; k++) {
+    // with a pivot limit, never queue more pivots than the limit still allows (+1 launch so that
+    // k_select can observe the exhausted budget): keeps no-op launches out of profiles
+    int nb = batch;
+    if (parm->it_lim >= 0) nb = std::max(1, std::min(batch, parm->it_lim - seen_pivots));
+    for (int k = 0; k < nb; k++) {
       launch_select(c.d_ctl, c.stream);
       if (c.prof) HIPCHECK(hipEventRecord(c.ev_pool[ev_used++], c.stream));
       launch_update(c.d_ctl, m, n, c.stream);
@@ -470,10 +476,14 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
     pull_stage(c, P, false);
     std::memcpy(&snap, c.h_stage, sizeof(Ctl));
     if (c.prof) {
-      // only the launches that really pivoted count: it_cnt advanced by (snap.it_cnt - before)
-      flush_update_events(c, ev_used);
+      // once the solve finishes inside a batch the queued-ahead launches are no-ops; only the
+      // leading launches that really stepped are timed
+      const int steps_now = snap.it_cnt + snap.n_flips;
+      flush_update_events(c, std::min(ev_used, (size_t)2 * (size_t)(steps_now - seen_steps)));
+      seen_steps = steps_now;
     }
     done = snap.done;
+    seen_pivots = snap.it_cnt;
     if (done == D_NEED_PHASE1) {
       // host-driven phase 1: per iteration head -> cost row (rowcomb) -> select -> update
       snap.done = D_RUN;

@@ -1,0 +1,97 @@
+"""CPU: the oracle against the committed HiGHS golden vectors (tests/golden/golden.json).
+
+The reference holds no fixtures and its LP arithmetic is GLPK's, absent
+here; the goldens come from an independent solver and pin status / objective / primal values.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mvolps_amd import capi, synth
+from mvolps_amd.capi import MAX
+
+from . import lpgen
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+RTOL = 1e-9
+
+
+def rel(a, b):
+    return abs(a - b) / max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("case", [g for g in GOLD["dense"] if g["m"] <= 1024], ids=lambda g: "%dx%d_s%d" % (g["m"], g["n"], g["seed"]))
+def test_dense_lp_objective_and_x(orc, case):
+    A, b, c = synth.dense_lp(case["m"], case["n"], case["seed"])
+    P = orc.create()
+    P.load_dense(A, b, c)
+    assert P.simplex() == 0
+    assert P.status == capi.OPT
+    assert rel(P.obj, case["obj"]) <= RTOL
+    x = P.col_prim()
+    assert np.all(x >= -1e-9) and np.all(A @ x <= b + 1e-7)
+    assert rel(float(c @ x), case["obj"]) <= RTOL
+    if "x" in case:
+        assert np.allclose(x, np.array(case["x"]), rtol=1e-7, atol=1e-8)
+
+
+def test_general_bounds_cases(orc):
+    rng = np.random.default_rng(7)
+    n_opt = 0
+    for g in GOLD["general"]:
+        A, row_b, col_b, c, direction = lpgen.random_general_lp(rng)
+        P = orc.create()
+        P.load_general(A, row_b, col_b, c, c0=1.5, direction=direction)
+        P.simplex()
+        lo, hi = lpgen.bounds_arrays(row_b)
+        cl, cu = lpgen.bounds_arrays(col_b)
+        if g["highs_status"] == 0:
+            n_opt += 1
+            assert P.status == capi.OPT, g["trial"]
+            assert rel(P.obj, g["obj"]) <= RTOL, g["trial"]
+            x = P.col_prim()
+            ra = A @ x
+            assert np.all(x >= cl - 1e-7) and np.all(x <= cu + 1e-7)
+            assert np.all(ra >= lo - 1e-7) and np.all(ra <= hi + 1e-7)
+            assert np.allclose(ra, P.row_prim(), atol=1e-8)
+        else:
+            # every case is feasible by construction, so "not optimal" can only mean unbounded
+            # (HiGHS reports some of these as status 2 from presolve; status 3 otherwise)
+            assert P.status == capi.UNBND, g["trial"]
+    assert n_opt >= 60
+
+
+def test_f1_lp_relaxation_and_ilp(orc):
+    """Config 1: LP relaxation 36.6667 at (0,0,17/3,5/3,4/3); ILP optimum 35."""
+    from oracle import oracle
+
+    f1 = GOLD["ilp"][0]
+    A, b, c = np.array(f1["A"]), np.array(f1["b"]), np.array(f1["c"])
+    P = lpgen.load_ilp(orc, A, b, c, np.inf)
+    P.simplex()
+    assert rel(P.obj, f1["lp_obj"]) <= RTOL
+    assert np.allclose(P.col_prim(), f1["lp_x"], atol=1e-9)
+    assert rel(P.obj, 110.0 / 3.0) <= RTOL
+    r = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, np.inf), quirks=0)
+    assert rel(r["best_lower"], f1["ilp_obj"]) <= RTOL and f1["ilp_obj"] == 35.0
+    assert np.allclose(r["x"], f1["ilp_x"], atol=1e-8)
+
+
+@pytest.mark.parametrize("case", GOLD["ilp"][1:], ids=lambda g: g["name"])
+def test_ilp_branch_and_bound_matches_milp(orc, case):
+    """Repaired mode (reference_quirks=0) must find the true ILP optimum, FIFO and best-bound alike."""
+    from oracle import oracle
+
+    A, b, c, U = synth.dense_ilp(case["m"], case["n"], case["seed"], int(case["U"]))
+    P = lpgen.load_ilp(orc, A, b, c, U)
+    P.simplex()
+    assert rel(P.obj, case["lp_obj"]) <= RTOL
+    strategies = (0, 1) if case["m"] <= 16 else (1,)
+    for ns in strategies:
+        r = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), node_strat=ns, quirks=0)
+        assert not r["hit_limit"]
+        assert rel(r["best_lower"], case["ilp_obj"]) <= RTOL
+        x = np.array(r["x"])
+        assert np.all(np.abs(x - np.round(x)) <= 1e-8) and np.all(A @ x <= b + 1e-7)
