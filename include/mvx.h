@@ -137,6 +137,9 @@ double mvx_profile_update_ms(void);
 long long mvx_profile_update_launches(void);
 /* wall time (ms, HIP events on the engine stream) of the last mvx_simplex call's device work */
 double mvx_last_solve_ms(const mvx_prob *P);
+/* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
+   for measurement sweeps -- results are identical for every setting */
+void mvx_set_tuning(int tr, int hot, int nt);
 /* block until all work queued on the engine stream has finished */
 void mvx_sync(void);
 

@@ -21,6 +21,7 @@ _EXTRA = {
     "profile_update_launches": (C.c_longlong, []),
     "last_solve_ms": (C.c_double, [C.c_void_p]),
     "sync": (None, []),
+    "set_tuning": (None, [C.c_int, C.c_int, C.c_int]),
 }
 
 _api = None

@@ -96,6 +96,7 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   dst->rtype = src->rtype; dst->rlb = src->rlb; dst->rub = src->rub;
   dst->ctype = src->ctype; dst->clb = src->clb; dst->cub = src->cub;
   dst->status = src->status; dst->it_cnt = src->it_cnt; dst->last_ms = 0.0;
+  dst->hint_dual = src->hint_dual;
   dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
   dst->sol_fresh = src->sol_fresh; dst->beta = src->beta; dst->dj = src->dj;
   mvx::engine_copy(dst, src);
@@ -397,6 +398,7 @@ int mvx_get_basis(const mvx_prob *P, int *head, int *nb, int *flag) {
 
 int mvx_device_count(void) { return mvx::device_count(); }
 int mvx_set_device(int dev) { return mvx::set_device(dev); }
+void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
 void mvx_profile_enable(int on) { mvx::profile_enable(on); }
 void mvx_profile_reset(void) { mvx::profile_reset(); }
 double mvx_profile_update_ms(void) { return mvx::profile_update_ms(); }

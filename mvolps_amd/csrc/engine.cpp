@@ -25,6 +25,12 @@ namespace mvx {
   } while (0)
 
 // kernel launch wrappers (kernels.hip)
+void set_tuning(int tr, int hot, int nt);
+int fused_npb(int n);
+int fused_nrb_max(int m);
+void launch_fboot(Ctl *, int n, hipStream_t);
+void launch_fa(Ctl *, int n, hipStream_t);
+void launch_fb(Ctl *, int m, int n, hipStream_t);
 void launch_select(Ctl *, hipStream_t);
 void launch_update(Ctl *, int m, int n, hipStream_t);
 void launch_p1_head(Ctl *, hipStream_t);
@@ -50,6 +56,8 @@ struct Context {
   void *scratch = nullptr;
   double *d_colq = nullptr, *d_srow = nullptr, *d_cost1 = nullptr, *d_wts = nullptr, *d_part = nullptr, *d_rcbase = nullptr;
   int *d_gflag = nullptr;
+  double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
+  Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
   size_t stage_bytes = 0;
   // slab recycling (B&B clones come and go at one size)
@@ -125,6 +133,10 @@ static void ensure_scratch(Context &c, int m_cap, int ld) {
   size_t o_colq = carve((size_t)(mc + 1) * 8), o_srow = carve((size_t)l * 8), o_cost1 = carve((size_t)l * 8);
   size_t o_wts = carve((size_t)(mc + 1) * 8), o_rcb = carve((size_t)l * 8), o_g = carve((size_t)(mc + 1) * 4);
   size_t o_part = carve((size_t)nchunks * l * 8);
+  size_t o_cx0 = carve((size_t)(mc + 1) * 8), o_cx1 = carve((size_t)(mc + 1) * 8);
+  size_t o_bc0 = carve((size_t)(mc + 1) * 8), o_bc1 = carve((size_t)(mc + 1) * 8);
+  size_t o_pp0 = carve((size_t)fused_npb(l) * sizeof(Cand)), o_pp1 = carve((size_t)fused_npb(l) * sizeof(Cand));
+  size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
   HIPCHECK(hipMalloc(&c.scratch, off));
   HIPCHECK(hipMemsetAsync(c.scratch, 0, off, c.stream));
   unsigned char *b = (unsigned char *)c.scratch;
@@ -135,6 +147,13 @@ static void ensure_scratch(Context &c, int m_cap, int ld) {
   c.d_rcbase = (double *)(b + o_rcb);
   c.d_gflag = (int *)(b + o_g);
   c.d_part = (double *)(b + o_part);
+  c.d_colqx[0] = (double *)(b + o_cx0);
+  c.d_colqx[1] = (double *)(b + o_cx1);
+  c.d_betac[0] = (double *)(b + o_bc0);
+  c.d_betac[1] = (double *)(b + o_bc1);
+  c.d_pp[0] = (Cand *)(b + o_pp0);
+  c.d_pp[1] = (Cand *)(b + o_pp1);
+  c.d_rp = (Cand *)(b + o_rp);
   c.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&c.d_stage, c.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&c.h_stage, c.stage_bytes));
@@ -233,7 +252,7 @@ static int ld_for(int n) { return (int)align_up((size_t)n + 1, LD_ALIGN); }
 
 // grow row capacity, preserving contents
 static void grow_rows(mvx_prob *P, int m_new) {
-  if (m_new <= P->m_cap) return;
+  if (m_new + ROW_SPARE <= P->m_cap) return;
   Context &c = ctx();
   const int cap = m_new + ROW_SLACK;
   void *o_slab = P->slab;
@@ -304,6 +323,11 @@ static void fill_ctl(Context &c, mvx_prob *P, Ctl *h) {
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = 1e-9; h->tol_dj = 1e-9; h->tol_piv = 1e-9;
   h->phase = PH_START; h->done = D_RUN; h->budget = -1;
+  h->colqx[0] = c.d_colqx[0]; h->colqx[1] = c.d_colqx[1];
+  h->betac[0] = c.d_betac[0]; h->betac[1] = c.d_betac[1];
+  h->pp[0] = c.d_pp[0]; h->pp[1] = c.d_pp[1]; h->rp = c.d_rp;
+  h->npb = fused_npb(P->n); h->nrb = 0; // nrb is published by k_fb (its grid height)
+  h->fstate = F_OFF;
 }
 
 static void upload_ctl(Context &c) {
@@ -346,7 +370,7 @@ static void build_slack_tableau(mvx_prob *P) {
   Context &c = ctx();
   const int m = P->m, n = P->n;
   const int ld = ld_for(n);
-  if (P->slab && (P->ld != ld || P->m_cap < m)) release_device(P);
+  if (P->slab && (P->ld != ld || P->m_cap < m + ROW_SPARE)) release_device(P);
   if (!P->slab) alloc_device(P, m + ROW_SLACK, ld);
   ensure_scratch(c, P->m_cap, P->ld);
   P->bvar.assign((size_t)m + 1, 0);
@@ -454,23 +478,47 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
   int done = D_RUN;
   int seen_steps = 0; // pivots + flips already accounted to the profile
   int seen_pivots = 0;
+  bool try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   Ctl snap;
   for (;;) {
     size_t ev_used = 0;
-    if (c.prof && c.ev_pool.size() < (size_t)2 * batch) { // sized for the largest batch
+    if (c.prof && c.ev_pool.size() < (size_t)2 * batch + 2) { // sized for the largest batch
       size_t old = c.ev_pool.size();
-      c.ev_pool.resize((size_t)2 * batch);
+      c.ev_pool.resize((size_t)2 * batch + 2);
       for (size_t k = old; k < c.ev_pool.size(); k++) HIPCHECK(hipEventCreate(&c.ev_pool[k]));
     }
     // with a pivot limit, never queue more pivots than the limit still allows (+1 launch so that
     // k_select can observe the exhausted budget): keeps no-op launches out of profiles
-    int nb = batch;
-    if (parm->it_lim >= 0) nb = std::max(1, std::min(batch, parm->it_lim - seen_pivots));
-    for (int k = 0; k < nb; k++) {
+    const int remaining = (parm->it_lim >= 0) ? std::max(0, parm->it_lim - seen_pivots) : (1 << 30);
+    auto ev = [&]() {
+      if (c.prof) HIPCHECK(hipEventRecord(c.ev_pool[ev_used++], c.stream));
+    };
+    if (try_fused) {
+      // one generic step settles the phase; if it is primal phase 2 the fused two-kernel pipeline
+      // (k_fa / k_fb) takes over, otherwise its launches return at once
       launch_select(c.d_ctl, c.stream);
-      if (c.prof) HIPCHECK(hipEventRecord(c.ev_pool[ev_used++], c.stream));
+      ev();
       launch_update(c.d_ctl, m, n, c.stream);
-      if (c.prof) HIPCHECK(hipEventRecord(c.ev_pool[ev_used++], c.stream));
+      ev();
+      const int nf = std::min(batch - 1, remaining - 1);
+      if (nf > 0) {
+        launch_fboot(c.d_ctl, n, c.stream);
+        launch_fb(c.d_ctl, m, n, c.stream);
+        for (int k = 0; k < nf; k++) {
+          launch_fa(c.d_ctl, n, c.stream);
+          ev();
+          launch_fb(c.d_ctl, m, n, c.stream);
+          ev();
+        }
+      }
+    } else {
+      const int nb = std::max(1, std::min(batch, remaining));
+      for (int k = 0; k < nb; k++) {
+        launch_select(c.d_ctl, c.stream);
+        ev();
+        launch_update(c.d_ctl, m, n, c.stream);
+        ev();
+      }
     }
     launch_export(c.d_ctl, c.d_stage, m, n, 0, c.stream);
     pull_stage(c, P, false);
@@ -484,6 +532,7 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
     }
     done = snap.done;
     seen_pivots = snap.it_cnt;
+    try_fused = (snap.phase == PH_PRIMAL2);
     if (done == D_NEED_PHASE1) {
       // host-driven phase 1: per iteration head -> cost row (rowcomb) -> select -> update
       snap.done = D_RUN;
@@ -534,6 +583,7 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
   HIPCHECK(hipEventElapsedTime(&ms, c.ev_a, c.ev_b));
   P->last_ms = ms;
   P->it_cnt += snap.it_cnt;
+  P->hint_dual = false;
   switch (done) {
     case D_OPT: P->status = MVX_OPT; return 0;
     case D_UNBND: P->status = MVX_UNBND; return 0;
@@ -552,6 +602,7 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
   const int pos = P->pos[k];
   if (pos > 0) {
     launch_set_basic_bounds(P->d_blb, P->d_bub, pos, lb, ub, c.stream);
+    P->hint_dual = true; // a basic variable's bound moved: the warm start is a dual one (bs.cpp:274,282)
   } else {
     const int jj = -pos;
     const double xo = nb_value(P->nflag[jj], old_lb, old_ub);
@@ -624,6 +675,7 @@ void engine_row_from_model(mvx_prob *P, int i) {
   }
   base[0] = b0;
   rowcomb_into_row(P, w, base, pos);
+  P->hint_dual = true; // appended cut rows (cut.cpp:40) leave the basis dual feasible
   P->sol_fresh = false;
   P->status = MVX_UNDEF;
 }
@@ -690,6 +742,15 @@ int engine_get_row(const mvx_prob *P, int row, double *out) {
   HIPCHECK(hipMemcpyAsync(out, P->d_T + (size_t)row * P->ld, (size_t)(P->n + 1) * 8, hipMemcpyDeviceToHost, c.stream));
   HIPCHECK(hipStreamSynchronize(c.stream));
   return 0;
+}
+
+void tuning(int tr, int hot, int nt) {
+  sync_stream();
+  set_tuning(tr, hot, nt);
+  if (g_ctx) { // partial-buffer sizes depend on the row-block depth
+    g_ctx->sc_m_cap = 0;
+    g_ctx->sc_ld = 0;
+  }
 }
 
 void profile_enable(int on) { ctx().prof = on != 0; }

@@ -26,6 +26,7 @@ void refresh_solution(const mvx_prob *P);
 int engine_get_tableau(const mvx_prob *P, double *out);
 int engine_get_row(const mvx_prob *P, int row, double *out); // out[0..n]
 
+void tuning(int tr, int hot, int nt);
 void profile_enable(int on);
 void profile_reset();
 double profile_update_ms();

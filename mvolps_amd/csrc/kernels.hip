@@ -20,11 +20,6 @@ namespace mvx {
 
 #define TIDX ((int)threadIdx.x)
 
-struct Cand {
-  double k1, k2;
-  int idx, aux;
-};
-
 // MODE 0: larger k1, then smaller idx.   MODE 1: smaller k1, then larger k2, then smaller idx.
 template <int MODE>
 __device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b) {
@@ -113,6 +108,40 @@ __device__ Cand dev_price(const Ctl *c, const double *cost, double sgn, Cand *ld
   return block_best<0>(best, lds);
 }
 
+// One row of the primal ratio test.  a = T[i][q], beta = T[i][0], gi = phase-1 sign (0 in phase 2).
+// Returns false when row i does not block.
+__device__ __forceinline__ bool ratio_row(double a, int sdir, double beta, double lb, double ub, int gi, double tp, int i,
+                                          Cand &x) {
+  const double aa = (sdir > 0) ? a : -a;
+  double t;
+  int up;
+  if (aa > tp) {
+    if (gi < 0) return false;
+    if (gi > 0) {
+      t = (lb - beta) / aa;
+      up = 0;
+    } else {
+      if (!(ub < INFINITY)) return false;
+      t = (ub - beta) / aa;
+      up = 1;
+    }
+  } else if (aa < -tp) {
+    if (gi > 0) return false;
+    if (gi < 0) {
+      t = (beta - ub) / (-aa);
+      up = 1;
+    } else {
+      if (!(lb > -INFINITY)) return false;
+      t = (beta - lb) / (-aa);
+      up = 0;
+    }
+  } else
+    return false;
+  if (t < 0.0) t = 0.0;
+  x = Cand{t, fabs(a), i, up};
+  return true;
+}
+
 // Primal ratio test for entering column q moving in direction sdir; also copies the pivot
 // column into colq[0..m].  g (nullable) = phase-1 infeasibility signs.
 __device__ Cand dev_primal_ratio(const Ctl *c, int q, int sdir, const int *g, Cand *lds) {
@@ -123,38 +152,8 @@ __device__ Cand dev_primal_ratio(const Ctl *c, int q, int sdir, const int *g, Ca
     const double a = c->T[(size_t)i * ld + q];
     c->colq[i] = a;
     if (i == 0) continue;
-    const double aa = (sdir > 0) ? a : -a;
-    const double beta = c->T[(size_t)i * ld];
-    const int gi = g ? g[i] : 0;
-    double t;
-    int up;
-    if (aa > tp) {
-      if (gi < 0) continue;
-      if (gi > 0) {
-        t = (c->blb[i] - beta) / aa;
-        up = 0;
-      } else {
-        const double ub = c->bub[i];
-        if (!(ub < INFINITY)) continue;
-        t = (ub - beta) / aa;
-        up = 1;
-      }
-    } else if (aa < -tp) {
-      if (gi > 0) continue;
-      if (gi < 0) {
-        t = (beta - c->bub[i]) / (-aa);
-        up = 1;
-      } else {
-        const double lb = c->blb[i];
-        if (!(lb > -INFINITY)) continue;
-        t = (beta - lb) / (-aa);
-        up = 0;
-      }
-    } else
-      continue;
-    if (t < 0.0) t = 0.0;
-    Cand x{t, fabs(a), i, up};
-    if (cand_better<1>(x, best)) best = x;
+    Cand x;
+    if (ratio_row(a, sdir, c->T[(size_t)i * ld], c->blb[i], c->bub[i], g ? g[i] : 0, tp, i, x) && cand_better<1>(x, best)) best = x;
   }
   return block_best<1>(best, lds);
 }
@@ -533,9 +532,360 @@ __global__ __launch_bounds__(256) void k_export(Ctl *c, unsigned char *stage, in
   }
 }
 
+// ======================================================================= fused primal path
+// Two multi-workgroup kernels per primal phase-2 pivot, no single-CU stage:
+//   k_fa  (one block per 256 columns): reduces the partials left by the previous step to the
+//         entering column q and leaving row p, scales the pivot row into srow, updates the
+//         objective row (so the NEXT entering column can be priced before the bulk update runs)
+//         and leaves new pricing partials.
+//   k_fb  (2-D grid over the tableau): the streamed rank-1 update; the lanes that own column 0
+//         and the next entering column also export them contiguously (betac / colqx) and leave
+//         per-row-block ratio-test partials for the next k_fa.
+// Every reduction key is a strict total order, so the redundant per-block reductions agree.
+// Arithmetic per entry is identical to k_select/k_update (and to the oracle).
+
+__device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, Cand &x) {
+  if (f == MVX_NS) return false;
+  const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
+  const bool dn = (f == MVX_NU || f == MVX_NF) && dj < -tol;
+  if (!up && !dn) return false;
+  x = Cand{fabs(dj), 0.0, j, up ? 1 : -1};
+  return true;
+}
+
+// wave-level reduce of an array of partials, result broadcast to all lanes
+template <int MODE>
+__device__ __forceinline__ Cand wave_reduce_partials(const Cand *arr, int cnt) {
+  const int lane = TIDX & 63;
+  Cand b{0.0, 0.0, 0, 0};
+  for (int k = lane; k < cnt; k += 64) {
+    Cand x = arr[k];
+    if (cand_better<MODE>(x, b)) b = x;
+  }
+  b = wave_best<MODE>(b);
+  Cand r;
+  r.k1 = __shfl(b.k1, 0, 64);
+  r.k2 = __shfl(b.k2, 0, 64);
+  r.idx = __shfl(b.idx, 0, 64);
+  r.aux = __shfl(b.aux, 0, 64);
+  return r;
+}
+
+// bootstrap: price the current objective row into pp[0]; arm the fused path
+__global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
+  __shared__ Cand lds[17];
+  if (c->done != D_RUN || c->phase != PH_PRIMAL2) {
+    if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
+    return;
+  }
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  Cand best{0.0, 0.0, 0, 0};
+  if (j >= 1 && j <= c->n) {
+    Cand x;
+    if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, x)) best = x;
+  }
+  best = block_best<0>(best, lds);
+  if (TIDX == 0) c->pp[0][blockIdx.x] = best;
+  if (blockIdx.x == 0 && TIDX == 0) {
+    c->fstate = F_RUN;
+    c->step = ST_NONE;
+    c->curB = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fa(Ctl *c) {
+  __shared__ Cand lds[17];
+  if (c->done != D_RUN || c->fstate != F_RUN) return;
+  const int cur = c->curA;
+  const bool lead = (blockIdx.x == 0 && TIDX == 0);
+  // entering column
+  Cand pc = wave_reduce_partials<0>(c->pp[cur], c->npb);
+  if (pc.idx == 0 || c->budget == 0) {
+    if (lead) c->fstate = F_STOP;
+    return;
+  }
+  const int q = pc.idx, sdir = pc.aux;
+  // leaving row
+  Cand rc = wave_reduce_partials<1>(c->rp, c->nrb);
+  const double lbq = c->nlb[q], ubq = c->nub[q];
+  const int fq = c->nflag[q];
+  const int n = c->n;
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  const double tol = c->tol_dj, sgn = c->sgn;
+  Cand best{0.0, 0.0, 0, 0};
+  if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+    const double tf = ubq - lbq;
+    if (rc.idx == 0 || tf <= rc.k1) {
+      // bound flip: tableau body and objective row unchanged; column q changes status
+      const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
+      if (j >= 1 && j <= n) {
+        Cand x;
+        if (price_col(j == q ? nf : c->nflag[j], sgn * c->T[j], tol, j, x)) best = x;
+      }
+      best = block_best<0>(best, lds);
+      if (TIDX == 0) c->pp[cur ^ 1][blockIdx.x] = best;
+      if (lead) {
+        c->step = ST_FLIP;
+        c->q = q;
+        c->sdir = sdir;
+        c->delta = (sdir > 0) ? tf : -tf;
+        c->flipflag = nf;
+        c->curB = cur;
+      }
+      return;
+    }
+  }
+  if (rc.idx == 0) {
+    if (lead) c->fstate = F_STOP; // unbounded ray: the generic path reports it
+    return;
+  }
+  const int p = rc.idx, p_up = rc.aux;
+  const double piv = c->colqx[cur][p];
+  const double bound = p_up ? c->bub[p] : c->blb[p];
+  const double dq = c->colqx[cur][0];
+  const int lf = dev_leave_flag(c->blb[p], c->bub[p], p_up);
+  if (j <= n) {
+    const double v = c->T[(size_t)p * c->ld + j];
+    const double s = (j == 0) ? (v - bound) / piv : v / piv;
+    c->srow[j] = s;
+    const double dold = c->T[j];
+    const double dnew = (j == q) ? dq / piv : fma(-dq, s, dold);
+    c->T[j] = dnew;
+    if (j >= 1) {
+      Cand x;
+      if (price_col(j == q ? lf : c->nflag[j], sgn * dnew, tol, j, x)) best = x;
+    }
+  }
+  best = block_best<0>(best, lds);
+  if (TIDX == 0) c->pp[cur ^ 1][blockIdx.x] = best;
+  if (lead) {
+    c->step = ST_PIVOT;
+    c->p = p;
+    c->q = q;
+    c->sdir = sdir;
+    c->p_up = p_up;
+    c->piv = piv;
+    c->bound = bound;
+    c->xq = dev_nb_value(fq, lbq, ubq);
+    c->leave_flag = lf;
+    c->ent_lb = lbq;
+    c->ent_ub = ubq;
+    c->curB = cur;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ double2 ld2(const double2 *p) {
+  if (NT) {
+    double2 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+  }
+  return *p;
+}
+template <int NT>
+__device__ __forceinline__ void st2(double2 *p, double2 v) {
+  if (NT) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+  } else
+    *p = v;
+}
+
+// Row block rb covers rows 1 + rb*TR .. (rb+1)*TR; row 0 (objective) belongs to k_fa.  The slab
+// always has at least 32 spare rows behind row m (mvx::ROW_SPARE), so the last block streams
+// whole tiles too: spare rows are never read by anything else and are re-zeroed when a cut row
+// is appended (k_add_rows).
+template <int TR, int HOT, int NT>
+__global__ __launch_bounds__(256) void k_fb(Ctl *c) {
+  if (c->done != D_RUN || c->fstate != F_RUN) return;
+  const int cur = c->curB, nxt = cur ^ 1;
+  const int step = c->step;
+  const int m = c->m, n = c->n, p = c->p, q = c->q;
+  const size_t ld = (size_t)c->ld;
+  const double piv = c->piv;
+  const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
+  const bool active = (j0 <= n);
+  const int i0 = 1 + (int)blockIdx.y * TR;
+  const bool has0 = (j0 == 0);
+  const bool tile0 = (blockIdx.x == 0);
+  const double *colq = c->colqx[cur];
+  double *bnew = c->betac[nxt];
+  if (step == ST_PIVOT) {
+    if (active) {
+      const double2 s = *reinterpret_cast<const double2 *>(c->srow + j0);
+      const bool q0 = (j0 == q), q1 = (j0 + 1 == q);
+      double *base = c->T + (size_t)i0 * ld + j0;
+      if (HOT == 1) {
+        // straight-line stream: every load issued before the first use
+        double2 v[TR];
+        double ci[TR];
+#pragma unroll
+        for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
+#pragma unroll
+        for (int r = 0; r < TR; r++) ci[r] = colq[i0 + r];
+#pragma unroll
+        for (int r = 0; r < TR; r++) {
+          v[r].x = fma(-ci[r], s.x, v[r].x);
+          v[r].y = fma(-ci[r], s.y, v[r].y);
+        }
+        if (q0 || q1) {
+          // only the wave that owns column q divides; the barrier keeps the division sequences
+          // (about 10 temporaries each) from being interleaved, so the kernel keeps its occupancy
+#pragma unroll
+          for (int r = 0; r < TR; r++) {
+            const double qv = ci[r] / piv;
+            if (q0) v[r].x = qv;
+            if (q1) v[r].y = qv;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (p >= i0 && p < i0 + TR) {
+#pragma unroll
+          for (int r = 0; r < TR; r++) {
+            if (i0 + r == p) {
+              v[r].x = q0 ? 1.0 / piv : -s.x;
+              v[r].y = q1 ? 1.0 / piv : -s.y;
+              if (has0) v[r].x = c->xq - s.x;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
+        if (has0) {
+#pragma unroll
+          for (int r = 0; r < TR; r++) bnew[i0 + r] = v[r].x;
+        }
+      } else {
+        for (int r = 0; r < TR; r++) {
+          const int i = i0 + r;
+          if (i > m) break;
+          double2 *ptr = reinterpret_cast<double2 *>(base + (size_t)r * ld);
+          double2 v = *ptr;
+          const double ci = colq[i];
+          if (i == p) {
+            v.x = q0 ? 1.0 / piv : -s.x;
+            v.y = q1 ? 1.0 / piv : -s.y;
+            if (has0) v.x = c->xq - s.x;
+          } else {
+            v.x = fma(-ci, s.x, v.x);
+            v.y = fma(-ci, s.y, v.y);
+            if (q0) v.x = ci / piv;
+            if (q1) v.y = ci / piv;
+          }
+          *ptr = v;
+          if (has0) bnew[i] = v.x;
+        }
+      }
+    }
+  } else if (tile0 && TIDX < TR && i0 + TIDX <= m) {
+    // bound flip: only column 0 moves; bootstrap: nothing moves.  One lane per row.
+    const int i = i0 + TIDX;
+    double *b0 = c->T + (size_t)i * ld;
+    double beta = *b0;
+    if (step == ST_FLIP) {
+      beta = fma(colq[i], c->delta, beta);
+      *b0 = beta;
+    }
+    bnew[i] = beta;
+  }
+  // next entering column (0 = none: k_fa will stop); reduced after the stream has been issued
+  const Cand nc = wave_reduce_partials<0>(c->pp[nxt], c->npb);
+  const int qn = nc.idx, sdn = nc.aux;
+  const bool tilen = (qn != 0 && (qn >> 9) == (int)blockIdx.x); // 512 columns per tile
+  if (tilen) {
+    // export the next entering column contiguously and leave this row block's ratio-test partial;
+    // one lane per row, values re-read after the block's own stores
+    __syncthreads();
+    if (TIDX < 64) {
+      Cand best{0.0, 0.0, 0, 0};
+      for (int r = TIDX; r < TR; r += 64) {
+        const int i = i0 + r;
+        if (i > m) break;
+        const double a = c->T[(size_t)i * ld + qn];
+        c->colqx[nxt][i] = a;
+        double beta, lb = c->blb[i], ub = c->bub[i];
+        if (step == ST_PIVOT) {
+          if (i == p) {
+            beta = c->xq - c->srow[0];
+            lb = c->ent_lb;
+            ub = c->ent_ub;
+          } else
+            beta = fma(-colq[i], c->srow[0], c->betac[cur][i]);
+        } else if (step == ST_FLIP) {
+          beta = fma(colq[i], c->delta, c->betac[cur][i]);
+        } else {
+          beta = c->T[(size_t)i * ld];
+        }
+        Cand x;
+        if (ratio_row(a, sdn, beta, lb, ub, 0, c->tol_piv, i, x) && cand_better<1>(x, best)) best = x;
+      }
+      best = wave_best<1>(best);
+      if (TIDX == 0) c->rp[blockIdx.y] = best;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && TIDX == 0) {
+    // objective row exports (row 0 is outside the row blocks)
+    double z = c->T[0];
+    if (step == ST_FLIP) {
+      z = fma(colq[0], c->delta, z);
+      c->T[0] = z;
+    }
+    bnew[0] = z;
+    if (qn != 0) c->colqx[nxt][0] = c->T[qn];
+    if (step == ST_PIVOT) {
+      const int kv = c->bvar[p];
+      const double klb = c->blb[p], kub = c->bub[p];
+      c->bvar[p] = c->nvar[q];
+      c->blb[p] = c->nlb[q];
+      c->bub[p] = c->nub[q];
+      c->nvar[q] = kv;
+      c->nlb[q] = klb;
+      c->nub[q] = kub;
+      c->nflag[q] = c->leave_flag;
+      c->it_cnt++;
+      if (c->budget > 0) c->budget--;
+    } else if (step == ST_FLIP) {
+      c->nflag[q] = c->flipflag;
+      c->n_flips++;
+    }
+    c->curA = nxt;
+    c->nrb = (int)gridDim.y; // number of ratio-test partials this launch leaves for k_fa
+  }
+}
+
 // ------------------------------------------------------------------ launch wrappers
 constexpr int UPDATE_TR = 16;
 
+// tuning knobs of the streamed update (mvx_set_tuning; defaults are the measured best)
+static int g_tr = 0, g_hot = 1, g_nt = 0; // g_tr 0 = pick from the grid size
+void set_tuning(int tr, int hot, int nt) {
+  g_tr = (tr == 8 || tr == 16 || tr == 32) ? tr : 0;
+  g_hot = hot ? 1 : 0;
+  g_nt = nt ? 1 : 0;
+}
+// row-block depth: 16 rows per block once that still gives every CU several blocks, else 8
+static int pick_tr(int m, int n) {
+  if (g_tr) return g_tr;
+  const long blocks16 = (long)((m + 15) / 16) * (((n + 2) / 2 + 255) / 256);
+  return blocks16 >= 2048 ? 16 : 8;
+}
+int fused_npb(int n) { return (n + 1 + 255) / 256; }
+int fused_nrb_max(int m) { return (m + 7) / 8; }
+void launch_fboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fboot, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
+void launch_fa(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fa, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
+void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
+  const int pairs = (n + 2) / 2;
+  const int tr = pick_tr(m, n);
+  dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
+#define FB_CASE(TR_, HOT_, NT_) \
+  if (tr == TR_ && g_hot == HOT_ && g_nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
+  FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
+  FB_CASE(8, 0, 0) FB_CASE(32, 0, 0) FB_CASE(8, 0, 1) FB_CASE(16, 0, 1) FB_CASE(32, 0, 1)
+#undef FB_CASE
+  std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
+}
 void launch_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, s, d_ctl); }
 void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s) {
   const int pairs = (n + 2) / 2;

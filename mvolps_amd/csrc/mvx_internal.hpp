@@ -21,6 +21,7 @@ namespace mvx {
 constexpr int ROWCOMB_CHUNK = 64; // rows per partial sum of k_rowcomb (fixed summation order)
 constexpr int LD_ALIGN = 32;      // doubles; 256-byte rows
 constexpr int ROW_SLACK = 64;     // spare tableau rows per handle for cut appends (cut.cpp:23)
+constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
 
 // state-machine phases (device-driven; mirrors orc_simplex's round loop)
 enum : int { PH_START = 0, PH_PRIMAL2 = 1, PH_DUAL = 2, PH_PHASE1 = 3 };
@@ -28,6 +29,14 @@ enum : int { PH_START = 0, PH_PRIMAL2 = 1, PH_DUAL = 2, PH_PHASE1 = 3 };
 enum : int { D_RUN = 0, D_OPT = 1, D_UNBND = 2, D_NOFEAS = 3, D_ITLIM = 4, D_PFEAS = 5, D_FAIL = 6, D_NEED_PHASE1 = 7 };
 // step kinds
 enum : int { ST_NONE = 0, ST_PIVOT = 1, ST_FLIP = 2 };
+// fused primal fast path state
+enum : int { F_OFF = 0, F_RUN = 1, F_STOP = 2 };
+
+// reduction candidate: (k1, k2, idx) is a strict total order, aux rides along
+struct Cand {
+  double k1, k2;
+  int idx, aux;
+};
 
 // Device-resident control block.  Kernels take only a pointer to it, so one launch
 // sequence (and one captured hipGraph) serves every problem handle.
@@ -52,7 +61,14 @@ struct Ctl {
   int it_cnt, n_flips;
   int step, p, q, sdir, p_up, leave_flag;
   double piv, bound, xq, delta;
-  int pad_[2];
+  // fused primal fast path (k_fboot / k_fa / k_fb): ping-pong buffers indexed by parity
+  double *colqx[2]; // [m_cap+1] contiguous copy of the NEXT pivot column, exported by k_fb
+  double *betac[2]; // [m_cap+1] contiguous copy of column 0 (basic values), exported by k_fb
+  Cand *pp[2];      // [npb] pricing partials (one per k_fa block)
+  Cand *rp;         // [nrb] ratio-test partials (one per k_fb row block)
+  int npb, nrb;
+  int fstate, curA, curB, flipflag;
+  double ent_lb, ent_ub;
 };
 
 struct HostModel; // forward
@@ -79,6 +95,7 @@ struct mvx_prob {
   int status = MVX_UNDEF;
   int it_cnt = 0;
   double last_ms = 0.0;
+  bool hint_dual = false; // last edit made a basic variable infeasible: start in the dual simplex
   // host mirrors of the basis (always in sync while valid)
   std::vector<int> bvar, nvar, nflag; // [m+1], [n+1], [n+1]
   std::vector<int> pos;               // pos[k], k=1..m+n: +row or -column
