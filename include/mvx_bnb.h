@@ -1,0 +1,118 @@
+/*
+ * mvx_bnb.h -- C ABI of the branch-and-bound driver that sits on top of the LP engine.
+ *
+ * The driver is the MI355X-side counterpart of MVOLPS's own code around glp_simplex:
+ *   branchAndBound      /root/reference/bs.cpp:54-348      (bs.h:7)
+ *   printInfo           /root/reference/util.cpp:414-473
+ *   pickNode / pickVar  /root/reference/util.cpp:154-230   (ParameterObj, util.h:61-99)
+ *   getFract            /root/reference/util.cpp:11-23
+ *   generateCut3        /root/reference/gmi.cpp:11-117     (gmi.h:7)
+ *   CutPool             /root/reference/cut.cpp:6-46       (cut.h:15-23)
+ *
+ * It talks to its LP engine only through `mvx_lp_api`, a table of exactly the GLPK-shaped
+ * entry points MVOLPS binds -- that table IS the drop-in boundary.
+ * mvx_hip_lp_api() returns the gfx950 engine's table (the only engine this library ships;
+ * passing NULL selects it).
+ */
+#ifndef MVX_BNB_H
+#define MVX_BNB_H
+
+#include "mvx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mvx_lp_api {
+  void *(*create_prob)(void);
+  void (*erase_prob)(void *P);
+  void (*delete_prob)(void *P);
+  void (*copy_prob)(void *dst, const void *src, int names);
+  int (*add_rows)(void *P, int nrs);
+  void (*set_mat_row)(void *P, int i, int len, const int *ind, const double *val);
+  void (*set_row_bnds)(void *P, int i, int type, double lb, double ub);
+  void (*set_col_bnds)(void *P, int j, int type, double lb, double ub);
+  int (*simplex)(void *P, const void *parm);
+  int (*get_status)(const void *P);
+  double (*get_obj_val)(const void *P);
+  double (*get_obj_coef)(const void *P, int j);
+  double (*get_col_prim)(const void *P, int j);
+  int (*get_num_rows)(const void *P);
+  int (*get_num_cols)(const void *P);
+  int (*get_col_kind)(const void *P, int j);
+  int (*get_col_stat)(const void *P, int j);
+  int (*get_row_stat)(const void *P, int i);
+  double (*get_row_ub)(const void *P, int i);
+  double (*get_col_ub)(const void *P, int j);
+  double (*get_col_lb)(const void *P, int j);
+  int (*get_col_type)(const void *P, int j);
+  int (*get_mat_row)(const void *P, int i, int *ind, double *val);
+  int (*eval_tab_row)(const void *P, int k, int *ind, double *val);
+  int (*get_it_cnt)(const void *P);
+} mvx_lp_api;
+
+const mvx_lp_api *mvx_hip_lp_api(void);
+
+/* ParameterObj (util.h:61-99); defaults VO / DFS(=FIFO) / no cuts (util.h:65-67) */
+typedef struct {
+  int var_strat;        /* 0 VO, 1 VFP, 2 VGO   (util.h:30) */
+  int node_strat;       /* 0 DFS (problems.front(), util.cpp:165), 1 BEST (util.cpp:170-186) */
+  int cut_strat;        /* 0 NONE, 1 GMI         (util.h:32) */
+  double cut_chance;    /* -cf: stored, never read (util.cpp:259-261) */
+  int loop_limit;       /* bs.cpp:320: 200000 branchings */
+  int max_nodes;        /* stop after this many loop iterations (<= 0: none) */
+  int reference_quirks; /* 1 (default): bug-compatible with bs.cpp / util.cpp;
+                           0: children keep the opposite bound (bs.cpp:274,282 drop it) and the
+                           integrality test has a 1e-9 tolerance */
+  int lazy_pool;        /* 1 (default): generate only the cut cut.cpp:20 will actually add (the last
+                           eligible column's); 0: generate and pool every cut like bs.cpp:250-255 */
+} mvx_bnb_params;
+
+/* B&B events at the emit points of bs.cpp (message.h EventType) */
+#define MVX_EV_PREGNANT 0   /* bs.cpp:119-129 */
+#define MVX_EV_INTEGER 1    /* bs.cpp:163-166 */
+#define MVX_EV_INFEASIBLE 2 /* bs.cpp:199-203 */
+#define MVX_EV_FATHOMED 3   /* bs.cpp:215-217 */
+#define MVX_EV_BRANCHED 4   /* bs.cpp:225-244 */
+#define MVX_EV_CANDIDATE 5  /* bs.cpp:300-318 */
+
+typedef struct {
+  int type, oid, pid, direction; /* direction 0 M, 1 R, 2 L (bs.cpp:43-52) */
+  double lp_bound;               /* field6 */
+  double sum_infeas;             /* field7 (bs.cpp:227-241) */
+  int n_violated;                /* field8 */
+  int pick;                      /* branching variable of a branched event, else 0 */
+} mvx_bnb_event;
+
+typedef struct {
+  int n_nodes;        /* oids are 1..n_nodes (util.h:17, util.cpp:29-30) */
+  int *parent;        /* parent[oid]; 0 for the root (bs.cpp:26-33) */
+  int *prune;         /* prune[oid]: 0 INTG, 1 FEAS, 3 BNDS, 4 NONE (util.h:27) */
+  double *node_bound; /* NodeData::upperBound */
+  int n_events;
+  mvx_bnb_event *events;
+  int count;          /* loop iterations (bs.cpp:326) */
+  int has_incumbent;
+  double best_lower;  /* bs.cpp:90,172-174 */
+  int incumbent_oid;
+  int n;
+  double *x;          /* x[1..n] of the incumbent (bs.cpp:181-187) */
+  long long total_pivots;
+  int hit_limit;
+} mvx_bnb_result;
+
+void mvx_bnb_default_params(mvx_bnb_params *p);
+/* int branchAndBound(glp_prob*, MVOLP::ParameterObj&)  bs.h:7 */
+int mvx_branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params *params, mvx_bnb_result *res);
+void mvx_bnb_free_result(mvx_bnb_result *res);
+
+double mvx_getFract(double x); /* util.cpp:11-23 */
+/* std::pair<int, std::vector<int>> printInfo(glp_prob*, bool)  util.cpp:414 */
+int mvx_printInfo(const mvx_lp_api *api, const void *prob, int quirks, int *violated, int *nviolated);
+/* CutContainer generateCut3(glp_prob*, int j)  gmi.h:7; inds/vals hold n+1 entries, returns -1 when rejected */
+int mvx_generateCut3(const mvx_lp_api *api, const void *prob, int j, int *inds, double *vals, double *lb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

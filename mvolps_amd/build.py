@@ -9,7 +9,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmvolps_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp", "bnb.cpp"]
 # -ffp-contract=off: fma() only where written, on host and device alike (bit-exact parity
 # with the CPU oracle)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-math-errno", "-Wall",

@@ -1,0 +1,503 @@
+// bnb.cpp -- branch-and-bound driver over the GLPK-shaped LP-engine table (include/mvx_bnb.h).
+//
+// Host-side mirror of MVOLPS's own control flow, same names and argument meaning:
+//   MVOLP::NodeData        util.cpp:25-42     MVOLP::ParameterObj::pickNode/pickVar  util.cpp:154-230
+//   printInfo              util.cpp:414-473   getFract                               util.cpp:11-23
+//   generateCut3           gmi.cpp:11-117     CutPool::addToPool/addCutConstraint    cut.cpp:6-46
+//   branchAndBound         bs.cpp:54-348      getParentOid / getBranchDirection      bs.cpp:26-52
+// Every LP call goes through `mvx_lp_api`; with the default table that is the gfx950 engine.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <memory>
+#include <utility>
+#include <vector>
+
+#include "../../include/mvx_bnb.h"
+
+namespace {
+
+struct CutContainer { // cut.h:7-13
+  std::vector<int> inds;
+  std::vector<double> vals;
+  double lb = 0.0;
+  int oid = 0;
+};
+
+class CutPool { // cut.h:15-23
+public:
+  explicit CutPool(const mvx_lp_api *api) : _api(api) {}
+  int addToPool(CutContainer cut) { // cut.cpp:6-9
+    _cuts.push_back(std::move(cut));
+    return (int)_cuts.size();
+  }
+  // the pool keeps only what addCutConstraint can ever read: its last element (cut.cpp:20)
+  void replaceLast(CutContainer cut) {
+    if (_cuts.empty()) _cuts.push_back(std::move(cut));
+    else _cuts.back() = std::move(cut);
+  }
+  int addCutConstraint(void *in, int cID = -1) { // cut.cpp:11-46
+    if (_cuts.empty()) return -1;
+    if (cID < 0) cID = (int)_cuts.size() - 1; // cut.cpp:20
+    const int index = _api->add_rows(in, 1);
+    const CutContainer &sel = _cuts.at((size_t)cID);
+    _api->set_mat_row(in, index, (int)sel.inds.size() - 1, sel.inds.data(), sel.vals.data()); // cut.cpp:40
+    _api->set_row_bnds(in, index, MVX_LO, sel.lb, 0);                                          // cut.cpp:43
+    return cID;
+  }
+
+private:
+  const mvx_lp_api *_api;
+  std::vector<CutContainer> _cuts;
+};
+
+double getFract(double x) { // util.cpp:11-23
+  double intPart;
+  double fractPart = std::modf(x, &intPart);
+  if (fractPart < 0.0) fractPart += 1;
+  return fractPart;
+}
+
+std::pair<int, std::vector<int>> printInfo(const mvx_lp_api *api, const void *prob, bool quirks) { // util.cpp:414-473
+  const int cols = api->get_num_cols(prob);
+  std::vector<int> violated;
+  const int status = api->get_status(prob);
+  if (status == MVX_NOFEAS || status == MVX_INFEAS || status == MVX_UNBND) return {-1, violated}; // util.cpp:424
+  for (int i = 1; i <= cols; i++) {
+    const double v = api->get_col_prim(prob, i);
+    if (!quirks) {
+      if (std::fabs(v - std::round(v)) > 1e-9 && api->get_col_kind(prob, i) != MVX_CV) violated.push_back(i);
+      continue;
+    }
+    if (v != 0 && api->get_obj_coef(prob, i) != 0) {                      // util.cpp:437
+      if (std::trunc(v) != v && api->get_col_kind(prob, i) != MVX_CV) {   // util.cpp:443-444
+        violated.push_back(i);
+      }
+    }
+  }
+  return {violated.empty() ? 1 : 0, violated};
+}
+
+// gmi.cpp:11-117.  oid stays -1 on rejection (gmi.cpp:20,25); on success the reference leaves it
+// indeterminate and bs.cpp:252 treats it as "not -1", which is what 0 reproduces.
+CutContainer generateCut3(const mvx_lp_api *api, const void *in, int j) {
+  CutContainer result;
+  double temp = 0.0; // uninitialised at gmi.cpp:13
+  const int m = api->get_num_rows(in);
+  const int n = api->get_num_cols(in);
+  if (api->get_col_kind(in, j) != MVX_IV || api->get_col_stat(in, j) != MVX_BS) {
+    result.oid = -1;
+    return result;
+  }
+  std::vector<double> work((size_t)m + n + 1, 0.0), val2((size_t)n + 1, 0.0);
+  std::vector<int> ind2((size_t)n + 1, 0);
+  const int len = api->eval_tab_row(in, m + j, ind2.data(), val2.data()); // gmi.cpp:36
+  double rhs = api->get_col_prim(in, j);                                   // gmi.cpp:37
+  for (int i = 1; i <= len; i++) {
+    const double val = val2[i];
+    int kind;
+    double ub;
+    if (ind2[i] <= m) { // gmi.cpp:42-47
+      kind = MVX_CV;
+      ub = api->get_row_ub(in, ind2[i]);
+    } else { // gmi.cpp:48-53
+      const int curCol = ind2[i] - m;
+      kind = api->get_col_kind(in, curCol);
+      ub = api->get_col_ub(in, curCol);
+    }
+    const double fRhs = getFract(rhs); // the RUNNING rhs (gmi.cpp:55,73)
+    const double fVal = getFract(val);
+    if (kind == MVX_IV) temp = (fRhs >= fVal) ? fVal : (fRhs / (1.0 - fRhs)) * (1.0 - fVal);
+    if (kind == MVX_CV) temp = (val >= 0.0) ? val : (fRhs / (1.0 - fRhs)) * (-1.0 * val);
+    work[ind2[i]] = -1.0 * temp; // gmi.cpp:72
+    rhs -= temp * ub;            // gmi.cpp:73
+  }
+  // gmi.cpp:81-89: back-substitution indexed by POSITION k in the row's non-zero list
+  std::vector<double> rv((size_t)n + 1);
+  std::vector<int> ri((size_t)n + 1);
+  for (int i = 1; i <= m; i++) {
+    if (work[i] == 0.0) continue; // adds work[i]*val == +-0 to finite sums: no effect on any bit
+    const int len2 = api->get_mat_row(in, i, ri.data(), rv.data());
+    const double wi = work[i];
+    for (int k = 1; k <= len2; k++) work[m + k] += wi * rv[k];
+  }
+  result.inds.resize((size_t)n + 1);
+  result.vals.resize((size_t)n + 1);
+  result.inds[0] = 0;
+  result.vals[0] = rhs;
+  for (int i = 1; i <= n; i++) {
+    result.inds[i] = i;
+    result.vals[i] = work[m + i];
+  }
+  result.lb = rhs;
+  result.oid = 0;
+  return result;
+}
+
+namespace MVOLP {
+enum PruneType { INTG = 0, FEAS = 1, BNDS = 3, NONE = 4 }; // util.h:27
+
+struct NodeData { // util.h:35-54
+  NodeData(const mvx_lp_api *api, const void *parent, int &idCounter) : _api(api) { // util.cpp:25-37
+    oid = idCounter;
+    idCounter += 1;
+    lowerBound = -std::numeric_limits<double>::infinity();
+    upperBound = std::numeric_limits<double>::infinity();
+    prob = _api->create_prob();
+    _api->copy_prob(prob, parent, MVX_ON);
+    inital = false;
+  }
+  ~NodeData() { _api->delete_prob(prob); } // util.cpp:39-42
+  NodeData(const NodeData &) = delete;
+  NodeData &operator=(const NodeData &) = delete;
+  double upperBound, lowerBound;
+  void *prob;
+  bool inital;
+  int oid;
+
+private:
+  const mvx_lp_api *_api;
+};
+
+class ParameterObj { // util.h:61-99
+public:
+  ParameterObj(const mvx_lp_api *api, const void *prob, const mvx_bnb_params &p) : _api(api), _prob(prob), _p(p) {}
+  bool IsCutEnabled() const { return _p.cut_strat != 0; }
+
+  std::shared_ptr<NodeData> pickNode(const std::deque<std::shared_ptr<NodeData>> &problems, int &index) const { // util.cpp:154-188
+    if (_p.node_strat == 0) { // "DFS" == FIFO
+      index = 0;
+      return problems.front();
+    }
+    index = 0;
+    for (int i = 1; i < (int)problems.size(); i++)
+      if (problems[(size_t)index]->upperBound < problems[(size_t)i]->upperBound) index = i; // first maximum
+    return problems.at((size_t)index);
+  }
+
+  int pickVar(const std::vector<int> &vars) const { // util.cpp:190-230
+    if (_p.var_strat == 0) return vars.front();
+    if (_p.var_strat == 1) {
+      // util.cpp:200-203 query _prob, the ROOT problem that is never solved
+      double curBest = std::fabs(getFract(_api->get_col_prim(_prob, vars.front())) - 0.5);
+      int index = vars.front();
+      for (int i : vars) {
+        const double cur = std::fabs(getFract(_api->get_col_prim(_prob, i)) - 0.5);
+        if (cur < curBest) {
+          curBest = cur;
+          index = i;
+        }
+      }
+      return index;
+    }
+    double bestCoef = 0.0;
+    int index = vars.front(); // uninitialised in the reference when no coefficient is > 0
+    for (int i : vars) {
+      const double cur = _api->get_obj_coef(_prob, i);
+      if (cur > bestCoef) {
+        bestCoef = cur;
+        index = i;
+      }
+    }
+    return index;
+  }
+
+private:
+  const mvx_lp_api *_api;
+  const void *_prob;
+  mvx_bnb_params _p;
+};
+} // namespace MVOLP
+
+int getBranchDirection(int oid) { // bs.cpp:43-52
+  if (oid <= 1) return 0;
+  return (oid % 2 == 0) ? 1 : 2;
+}
+
+struct Recorder {
+  std::vector<int> parent, prune;
+  std::vector<double> bound;
+  std::vector<mvx_bnb_event> events;
+  long long pivots = 0;
+  void node(int oid, int pid) {
+    if ((int)parent.size() <= oid) {
+      parent.resize((size_t)oid + 1, 0);
+      prune.resize((size_t)oid + 1, MVOLP::NONE);
+      bound.resize((size_t)oid + 1, std::numeric_limits<double>::infinity());
+    }
+    parent[(size_t)oid] = pid;
+  }
+  void emit(int type, int oid, double f6, double f7, int f8, int pick) {
+    mvx_bnb_event e;
+    e.type = type;
+    e.oid = oid;
+    e.pid = parent[(size_t)oid]; // getParentOid, bs.cpp:26-33
+    e.direction = getBranchDirection(oid);
+    e.lp_bound = f6;
+    e.sum_infeas = f7;
+    e.n_violated = f8;
+    e.pick = pick;
+    events.push_back(e);
+  }
+};
+
+int solve(const mvx_lp_api *api, void *p, Recorder &rec) {
+  const int before = api->get_it_cnt(p);
+  const int rc = api->simplex(p, nullptr); // the reference ignores the return code
+  rec.pivots += api->get_it_cnt(p) - before;
+  return rc;
+}
+
+template <typename T>
+T *dup(const std::vector<T> &v) {
+  T *p = (T *)std::malloc(sizeof(T) * (v.empty() ? 1 : v.size()));
+  if (!v.empty()) std::memcpy(p, v.data(), sizeof(T) * v.size());
+  return p;
+}
+
+int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm, mvx_bnb_result *res) { // bs.cpp:54
+  MVOLP::ParameterObj params(api, prob, prm);
+  CutPool pool(api);
+  Recorder rec;
+  int id = 1; // util.h:17
+  const bool quirks = prm.reference_quirks != 0;
+
+  std::deque<std::shared_ptr<MVOLP::NodeData>> leafContainer;
+  auto S1 = std::make_shared<MVOLP::NodeData>(api, prob, id); // bs.cpp:80
+  S1->inital = true;
+  rec.node(S1->oid, 0);
+  leafContainer.push_back(S1);
+
+  void *a = api->create_prob();                                 // bs.cpp:89
+  double bestLower = -std::numeric_limits<double>::infinity();  // bs.cpp:90
+  const int n0 = api->get_num_cols(prob);
+  std::vector<double> xbest((size_t)n0 + 1, 0.0);
+  int incumbent_oid = 0, has_incumbent = 0, hit_limit = 0;
+  int count = 0;
+
+  while (!leafContainer.empty()) { // bs.cpp:96
+    if (prm.max_nodes > 0 && count >= prm.max_nodes) {
+      hit_limit = 1;
+      break;
+    }
+    int index;
+    std::shared_ptr<MVOLP::NodeData> node = params.pickNode(leafContainer, index); // bs.cpp:101
+    api->erase_prob(a);                       // bs.cpp:114-115
+    api->copy_prob(a, node->prob, MVX_OFF);   // bs.cpp:116
+    solve(api, a, rec);                       // bs.cpp:117
+    rec.emit(MVX_EV_PREGNANT, node->oid, api->get_obj_val(a), 0.0, 0, 0); // bs.cpp:119-129
+
+    auto ret = printInfo(api, a, quirks); // bs.cpp:135|151
+    const int status = ret.first;
+    const std::vector<int> &vars = ret.second;
+    if (node->inital) {
+      if (status == -1) { // bs.cpp:139-143
+        rec.prune[(size_t)node->oid] = MVOLP::FEAS;
+        break;
+      }
+      if (status == 1) { // bs.cpp:144-149
+        node->upperBound = api->get_obj_val(a);
+        rec.bound[(size_t)node->oid] = node->upperBound;
+        rec.prune[(size_t)node->oid] = MVOLP::INTG;
+        break;
+      }
+    }
+    node->upperBound = api->get_obj_val(a); // bs.cpp:156
+    rec.bound[(size_t)node->oid] = node->upperBound;
+
+    if (status == 1) { // prune by integrality, bs.cpp:158-193
+      rec.prune[(size_t)node->oid] = MVOLP::INTG;
+      rec.emit(MVX_EV_INTEGER, node->oid, node->upperBound, 0.0, 0, 0);
+      if (node->upperBound > bestLower) {
+        bestLower = node->upperBound;
+        has_incumbent = 1;
+        incumbent_oid = node->oid;
+        const int na = api->get_num_cols(a);
+        for (int i = 1; i <= na && i <= n0; i++) xbest[(size_t)i] = api->get_col_prim(a, i);
+      }
+      leafContainer.erase(leafContainer.begin() + index);
+    } else if (status == -1) { // bs.cpp:194-209
+      rec.prune[(size_t)node->oid] = MVOLP::FEAS;
+      rec.emit(MVX_EV_INFEASIBLE, node->oid, 0.0, 0.0, 0, 0);
+      leafContainer.erase(leafContainer.begin() + index);
+    } else if (api->get_obj_val(a) <= bestLower) { // bs.cpp:210-223 (ties pruned)
+      rec.prune[(size_t)node->oid] = MVOLP::BNDS;
+      rec.emit(MVX_EV_FATHOMED, node->oid, 0.0, 0.0, 0, 0);
+      leafContainer.erase(leafContainer.begin() + index);
+    } else { // branch, bs.cpp:224-324
+      double acc = 0;
+      for (int i : vars)
+        if (i != 0) acc += getFract(api->get_col_prim(a, i)); // bs.cpp:229-233
+      leafContainer.erase(leafContainer.begin() + index);       // bs.cpp:247
+
+      if (params.IsCutEnabled()) { // bs.cpp:249-258
+        const int na = api->get_num_cols(a);
+        if (prm.lazy_pool) {
+          // only the pool's LAST cut is ever added (cut.cpp:20): generate just that one
+          for (int j = na; j >= 1; j--) {
+            if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) {
+              pool.replaceLast(generateCut3(api, a, j));
+              break;
+            }
+          }
+        } else {
+          for (int j = 1; j <= na; j++) {
+            CutContainer result = generateCut3(api, a, j);
+            if (result.oid != -1) pool.addToPool(std::move(result));
+          }
+        }
+        pool.addCutConstraint(a);
+      }
+      const int pick = params.pickVar(vars);         // bs.cpp:260
+      const double bound = api->get_col_prim(a, pick); // bs.cpp:261
+      rec.emit(MVX_EV_BRANCHED, node->oid, node->upperBound, acc, (int)vars.size(), pick);
+
+      auto S2 = std::make_shared<MVOLP::NodeData>(api, a, id); // bs.cpp:269-273
+      auto S3 = std::make_shared<MVOLP::NodeData>(api, a, id);
+      rec.node(S2->oid, node->oid);
+      rec.node(S3->oid, node->oid);
+      if (quirks) {
+        api->set_col_bnds(S2->prob, pick, MVX_UP, 0, std::floor(bound)); // bs.cpp:274
+      } else {
+        const int t = api->get_col_type(a, pick);
+        const double l = api->get_col_lb(a, pick);
+        if (t == MVX_LO || t == MVX_DB || t == MVX_FX)
+          api->set_col_bnds(S2->prob, pick, (l == std::floor(bound)) ? MVX_FX : MVX_DB, l, std::floor(bound));
+        else
+          api->set_col_bnds(S2->prob, pick, MVX_UP, 0, std::floor(bound));
+      }
+      solve(api, S2->prob, rec); // bs.cpp:279
+      S2->upperBound = api->get_obj_val(S2->prob);
+      if (quirks) {
+        api->set_col_bnds(S3->prob, pick, MVX_LO, std::ceil(bound), 0); // bs.cpp:282
+      } else {
+        const int t = api->get_col_type(a, pick);
+        const double u = api->get_col_ub(a, pick);
+        if (t == MVX_UP || t == MVX_DB || t == MVX_FX)
+          api->set_col_bnds(S3->prob, pick, (u == std::ceil(bound)) ? MVX_FX : MVX_DB, std::ceil(bound), u);
+        else
+          api->set_col_bnds(S3->prob, pick, MVX_LO, std::ceil(bound), 0);
+      }
+      solve(api, S3->prob, rec); // bs.cpp:287
+      S3->upperBound = api->get_obj_val(S3->prob);
+      rec.bound[(size_t)S2->oid] = S2->upperBound;
+      rec.bound[(size_t)S3->oid] = S3->upperBound;
+
+      leafContainer.push_back(S2); // bs.cpp:297-298
+      leafContainer.push_back(S3);
+      rec.emit(MVX_EV_CANDIDATE, S2->oid, S2->upperBound, 0.0, 0, 0); // bs.cpp:300-318
+      rec.emit(MVX_EV_CANDIDATE, S3->oid, S3->upperBound, 0.0, 0, 0);
+      if (count > prm.loop_limit) { // bs.cpp:320-323 calls std::exit(-1); here the run stops
+        hit_limit = 1;
+        count++;
+        break;
+      }
+    }
+    count++; // bs.cpp:326
+  }
+  leafContainer.clear();
+  api->delete_prob(a);
+
+  std::memset(res, 0, sizeof(*res));
+  res->n_nodes = id - 1;
+  res->parent = dup(rec.parent);
+  res->prune = dup(rec.prune);
+  res->node_bound = dup(rec.bound);
+  res->n_events = (int)rec.events.size();
+  res->events = dup(rec.events);
+  res->count = count;
+  res->has_incumbent = has_incumbent;
+  res->best_lower = bestLower;
+  res->incumbent_oid = incumbent_oid;
+  res->n = n0;
+  res->x = dup(xbest);
+  res->total_pivots = rec.pivots;
+  res->hit_limit = hit_limit;
+  return 0;
+}
+
+// ---- the gfx950 engine's table ----
+const mvx_lp_api g_hip_api = {
+    []() -> void * { return mvx_create_prob(); },
+    [](void *P) { mvx_erase_prob((mvx_prob *)P); },
+    [](void *P) { mvx_delete_prob((mvx_prob *)P); },
+    [](void *d, const void *s, int names) { mvx_copy_prob((mvx_prob *)d, (const mvx_prob *)s, names); },
+    [](void *P, int nrs) { return mvx_add_rows((mvx_prob *)P, nrs); },
+    [](void *P, int i, int len, const int *ind, const double *val) { mvx_set_mat_row((mvx_prob *)P, i, len, ind, val); },
+    [](void *P, int i, int t, double lb, double ub) { mvx_set_row_bnds((mvx_prob *)P, i, t, lb, ub); },
+    [](void *P, int j, int t, double lb, double ub) { mvx_set_col_bnds((mvx_prob *)P, j, t, lb, ub); },
+    [](void *P, const void *parm) { return mvx_simplex((mvx_prob *)P, (const mvx_smcp *)parm); },
+    [](const void *P) { return mvx_get_status((const mvx_prob *)P); },
+    [](const void *P) { return mvx_get_obj_val((const mvx_prob *)P); },
+    [](const void *P, int j) { return mvx_get_obj_coef((const mvx_prob *)P, j); },
+    [](const void *P, int j) { return mvx_get_col_prim((const mvx_prob *)P, j); },
+    [](const void *P) { return mvx_get_num_rows((const mvx_prob *)P); },
+    [](const void *P) { return mvx_get_num_cols((const mvx_prob *)P); },
+    [](const void *P, int j) { return mvx_get_col_kind((const mvx_prob *)P, j); },
+    [](const void *P, int j) { return mvx_get_col_stat((const mvx_prob *)P, j); },
+    [](const void *P, int i) { return mvx_get_row_stat((const mvx_prob *)P, i); },
+    [](const void *P, int i) { return mvx_get_row_ub((const mvx_prob *)P, i); },
+    [](const void *P, int j) { return mvx_get_col_ub((const mvx_prob *)P, j); },
+    [](const void *P, int j) { return mvx_get_col_lb((const mvx_prob *)P, j); },
+    [](const void *P, int j) { return mvx_get_col_type((const mvx_prob *)P, j); },
+    [](const void *P, int i, int *ind, double *val) { return mvx_get_mat_row((const mvx_prob *)P, i, ind, val); },
+    [](const void *P, int k, int *ind, double *val) { return mvx_eval_tab_row((const mvx_prob *)P, k, ind, val); },
+    [](const void *P) { return mvx_get_it_cnt((const mvx_prob *)P); },
+};
+
+} // namespace
+
+extern "C" {
+
+const mvx_lp_api *mvx_hip_lp_api(void) { return &g_hip_api; }
+
+void mvx_bnb_default_params(mvx_bnb_params *p) {
+  p->var_strat = 0;  // util.h:65
+  p->node_strat = 0; // util.h:66
+  p->cut_strat = 0;  // util.h:67
+  p->cut_chance = 0.0;
+  p->loop_limit = 200000; // bs.cpp:320
+  p->max_nodes = 0;
+  p->reference_quirks = 1;
+  p->lazy_pool = 1;
+}
+
+int mvx_branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params *params, mvx_bnb_result *res) {
+  mvx_bnb_params dflt;
+  if (!params) {
+    mvx_bnb_default_params(&dflt);
+    params = &dflt;
+  }
+  return branchAndBound(api ? api : &g_hip_api, prob, *params, res);
+}
+
+void mvx_bnb_free_result(mvx_bnb_result *res) {
+  std::free(res->parent);
+  std::free(res->prune);
+  std::free(res->node_bound);
+  std::free(res->events);
+  std::free(res->x);
+  std::memset(res, 0, sizeof(*res));
+}
+
+double mvx_getFract(double x) { return getFract(x); }
+
+int mvx_printInfo(const mvx_lp_api *api, const void *prob, int quirks, int *violated, int *nviolated) {
+  auto r = printInfo(api ? api : &g_hip_api, prob, quirks != 0);
+  *nviolated = (int)r.second.size();
+  for (size_t k = 0; k < r.second.size(); k++) violated[k] = r.second[k];
+  return r.first;
+}
+
+int mvx_generateCut3(const mvx_lp_api *api, const void *prob, int j, int *inds, double *vals, double *lb) {
+  CutContainer c = generateCut3(api ? api : &g_hip_api, prob, j);
+  if (c.oid == -1) return -1;
+  std::memcpy(inds, c.inds.data(), c.inds.size() * sizeof(int));
+  std::memcpy(vals, c.vals.data(), c.vals.size() * sizeof(double));
+  *lb = c.lb;
+  return 0;
+}
+
+} // extern "C"

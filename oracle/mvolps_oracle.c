@@ -579,7 +579,7 @@ static void pivot(orc_prob *P, int p, int q, double bound, int leave_flag) {
   double *s = (double *)xcalloc((size_t)n + 1, sizeof(double));
   s[0] = (rowp[0] - bound) / piv;
   for (int j = 1; j <= n; j++) s[j] = rowp[j] / piv;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((long)m * n >= 262144)
   for (int i = 0; i <= m; i++) {
     if (i == p) continue;
     double *row = &P->T[(size_t)i * ld];

@@ -68,6 +68,9 @@ _api = None
 def api():
     global _api
     if _api is None:
+        # row-parallel update threads (large tableaux only); a GPU box reports far more cores than
+        # a job may use, so never inherit the machine-wide default
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 8)))
         lib = C.CDLL(build())
         extra = {
             "getFract": (C.c_double, [C.c_double]),

@@ -3,7 +3,7 @@ import json
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mvolps_amd
 from mvolps_amd import synth
 
