@@ -30,6 +30,23 @@ def bytes_per_pivot(m, n):
     return 16 * (m + 1) * (n + 1)
 
 
+def pmc_traffic(m, n):
+    """HBM bytes per k_fb launch from the committed rocprofv3 PMC passes (profiles/*traffic*.json,
+    written by scripts/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when not measured."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("m") == m and d.get("n") == n and d.get("bytes_per_launch"):
+            best = d["bytes_per_launch"]
+    return best
+
+
 def cpu_baseline(m, n, seed, budget_s=12.0, max_pivots=400):
     """Oracle (CPU restatement, OpenMP row-parallel update) on a bounded sample of the same LP."""
     threads = min(os.cpu_count() or 1, 16)
@@ -124,7 +141,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el_max = float(t.item())
 
-    # per-kernel pass: HIP events around every k_update launch, on the engine's own stream
+    # per-kernel pass: HIP events around every k_fb launch, on the engine's own stream
     roof = None
     if rank == 0:
         api.profile_reset()
@@ -141,12 +158,12 @@ def main():
             achieved = bytes_per_pivot(m, n) / (avg_ms * 1e-3) / 1e9
             roof = {
                 "bound": "hbm",
-                "kernel": "k_update",
+                "kernel": "k_fb (streamed Gauss-Jordan rank-1 update)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(m, n),
                 "avg_launch_us": avg_ms * 1e3,
                 "launches_timed": pivots,
                 "bytes_per_launch": bytes_per_pivot(m, n),

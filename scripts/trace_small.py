@@ -7,5 +7,5 @@ api = mvolps_amd.api()
 A, b, c = synth.dense_lp(m, n, 12345)
 P = api.create(); P.load_dense(A, b, c)
 P.simplex(it_lim=30)
-P.simplex(it_lim=200)
+P.simplex(it_lim=int(sys.argv[3]) if len(sys.argv) > 3 else 200)
 print(P.it_cnt)
