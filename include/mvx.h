@@ -137,6 +137,12 @@ double mvx_profile_update_ms(void);
 long long mvx_profile_update_launches(void);
 /* wall time (ms, HIP events on the engine stream) of the last mvx_simplex call's device work */
 double mvx_last_solve_ms(const mvx_prob *P);
+/* node migration between ranks: image of bounds + basis + tableau in DEVICE
+   memory of this process's GPU, ready for an RCCL send; the receiver rebuilds the handle on top of
+   its own copy `base` of the root model (appended cut rows are not carried) */
+long long mvx_pack_size(const mvx_prob *P);
+int mvx_pack(const mvx_prob *P, void *dev_buf);
+int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf);
 /* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
    for measurement sweeps -- results are identical for every setting */
 void mvx_set_tuning(int tr, int hot, int nt);

@@ -398,6 +398,19 @@ int mvx_get_basis(const mvx_prob *P, int *head, int *nb, int *flag) {
 
 int mvx_device_count(void) { return mvx::device_count(); }
 int mvx_set_device(int dev) { return mvx::set_device(dev); }
+long long mvx_pack_size(const mvx_prob *P) { return mvx::engine_pack_size(P); }
+int mvx_pack(const mvx_prob *P, void *dev_buf) { return mvx::engine_pack(P, dev_buf); }
+int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
+  if (dst == base) return -1;
+  // model rows / objective / kinds come from the receiver's own copy of the root problem
+  mvx::release_device(dst);
+  dst->m = base->m; dst->n = base->n; dst->dir = base->dir;
+  dst->A = base->A; dst->c = base->c; dst->kind = base->kind; dst->cname = base->cname;
+  dst->rtype = base->rtype; dst->rlb = base->rlb; dst->rub = base->rub;
+  dst->ctype = base->ctype; dst->clb = base->clb; dst->cub = base->cub;
+  dst->valid = false; dst->sol_fresh = false;
+  return mvx::engine_unpack(dst, dev_buf);
+}
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
 void mvx_profile_enable(int on) { mvx::profile_enable(on); }
 void mvx_profile_reset(void) { mvx::profile_reset(); }

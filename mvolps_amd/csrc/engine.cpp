@@ -744,6 +744,124 @@ int engine_get_row(const mvx_prob *P, int row, double *out) {
   return 0;
 }
 
+// ------------------------------------------------------------------ pack / unpack (migration)
+// Device-side image of a handle for node migration between ranks:
+//   [PackHdr][ctype,rtype,bvar,nvar,nflag i32][clb,cub,rlb,rub f64] pad 256 | T live rows | slab tail
+struct PackHdr {
+  long long magic, m, n, ld, m_cap, status, it_cnt, valid, hint_dual, host_bytes, reserved[2];
+};
+static const long long PACK_MAGIC = 0x4d56584849504bll;
+
+static size_t pack_host_bytes(int m, int n) {
+  size_t sz = sizeof(PackHdr);
+  sz += sizeof(int) * ((size_t)(n + 1) + 2 * (size_t)(m + 1) + 2 * (size_t)(n + 1));
+  sz = align_up(sz, 8);
+  sz += sizeof(double) * (2 * (size_t)(n + 1) + 2 * (size_t)(m + 1));
+  return align_up(sz, 256);
+}
+
+long long engine_pack_size(const mvx_prob *P) {
+  size_t sz = pack_host_bytes(P->m, P->n);
+  if (P->valid) {
+    SlabLayout L = slab_layout(P->m_cap, P->ld);
+    sz += align_up((size_t)(P->m + 1) * P->ld * 8, 256) + (L.total - L.o_bvar);
+  }
+  return (long long)sz;
+}
+
+int engine_pack(const mvx_prob *P, void *dev_buf) {
+  Context &c = ctx();
+  const int m = P->m, n = P->n;
+  const size_t hb = pack_host_bytes(m, n);
+  std::vector<unsigned char> host(hb, 0);
+  unsigned char *b = host.data();
+  PackHdr h{};
+  h.magic = PACK_MAGIC; h.m = m; h.n = n; h.ld = P->ld; h.m_cap = P->m_cap; h.status = P->status;
+  h.it_cnt = P->it_cnt; h.valid = P->valid; h.hint_dual = P->hint_dual; h.host_bytes = (long long)hb;
+  std::memcpy(b, &h, sizeof(h));
+  b += sizeof(h);
+  unsigned char *b0 = b;
+  auto put = [&](const void *src, size_t bytes) {
+    if (src) std::memcpy(b, src, bytes);
+    b += bytes;
+  };
+  put(P->ctype.data(), sizeof(int) * (n + 1));
+  put(P->rtype.data(), sizeof(int) * (m + 1));
+  put(P->valid ? P->bvar.data() : nullptr, sizeof(int) * (m + 1));
+  put(P->valid ? P->nvar.data() : nullptr, sizeof(int) * (n + 1));
+  put(P->valid ? P->nflag.data() : nullptr, sizeof(int) * (n + 1));
+  b = b0 + align_up((size_t)(b - b0), 8);
+  put(P->clb.data(), 8 * (size_t)(n + 1));
+  put(P->cub.data(), 8 * (size_t)(n + 1));
+  put(P->rlb.data(), 8 * (size_t)(m + 1));
+  put(P->rub.data(), 8 * (size_t)(m + 1));
+  unsigned char *d = (unsigned char *)dev_buf;
+  HIPCHECK(hipMemcpyAsync(d, host.data(), hb, hipMemcpyHostToDevice, c.stream));
+  if (P->valid) {
+    SlabLayout L = slab_layout(P->m_cap, P->ld);
+    const size_t tb = (size_t)(m + 1) * P->ld * 8;
+    HIPCHECK(hipMemcpyAsync(d + hb, P->d_T, tb, hipMemcpyDeviceToDevice, c.stream));
+    HIPCHECK(hipMemcpyAsync(d + hb + align_up(tb, 256), (const unsigned char *)P->slab + L.o_bvar, L.total - L.o_bvar,
+                            hipMemcpyDeviceToDevice, c.stream));
+  }
+  HIPCHECK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// dst must already hold a copy of the receiver's root MODEL (rows, objective, kinds)
+int engine_unpack(mvx_prob *dst, const void *dev_buf) {
+  Context &c = ctx();
+  const unsigned char *d = (const unsigned char *)dev_buf;
+  PackHdr h;
+  HIPCHECK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+  HIPCHECK(hipStreamSynchronize(c.stream));
+  if (h.magic != PACK_MAGIC || h.m != dst->m || h.n != dst->n) return -1;
+  const int m = (int)h.m, n = (int)h.n;
+  std::vector<unsigned char> host((size_t)h.host_bytes);
+  HIPCHECK(hipMemcpyAsync(host.data(), d, (size_t)h.host_bytes, hipMemcpyDeviceToHost, c.stream));
+  HIPCHECK(hipStreamSynchronize(c.stream));
+  const unsigned char *b = host.data() + sizeof(PackHdr);
+  const unsigned char *b0 = b;
+  auto get = [&](void *dstp, size_t bytes) {
+    if (dstp) std::memcpy(dstp, b, bytes);
+    b += bytes;
+  };
+  get(dst->ctype.data(), sizeof(int) * (n + 1));
+  get(dst->rtype.data(), sizeof(int) * (m + 1));
+  if (h.valid) {
+    dst->bvar.assign((size_t)m + 1, 0);
+    dst->nvar.assign((size_t)n + 1, 0);
+    dst->nflag.assign((size_t)n + 1, 0);
+  }
+  get(h.valid ? dst->bvar.data() : nullptr, sizeof(int) * (m + 1));
+  get(h.valid ? dst->nvar.data() : nullptr, sizeof(int) * (n + 1));
+  get(h.valid ? dst->nflag.data() : nullptr, sizeof(int) * (n + 1));
+  b = b0 + align_up((size_t)(b - b0), 8);
+  get(dst->clb.data(), 8 * (size_t)(n + 1));
+  get(dst->cub.data(), 8 * (size_t)(n + 1));
+  get(dst->rlb.data(), 8 * (size_t)(m + 1));
+  get(dst->rub.data(), 8 * (size_t)(m + 1));
+  dst->status = (int)h.status;
+  dst->it_cnt = (int)h.it_cnt;
+  dst->hint_dual = h.hint_dual != 0;
+  dst->sol_fresh = false;
+  release_device(dst);
+  dst->valid = false;
+  if (h.valid) {
+    SlabLayout L = slab_layout((int)h.m_cap, (int)h.ld);
+    void *slab = slab_alloc(c, L.total);
+    bind_slab(dst, slab, (int)h.m_cap, (int)h.ld);
+    const size_t tb = (size_t)(m + 1) * dst->ld * 8;
+    HIPCHECK(hipMemcpyAsync(dst->d_T, d + h.host_bytes, tb, hipMemcpyDeviceToDevice, c.stream));
+    HIPCHECK(hipMemcpyAsync((unsigned char *)slab + L.o_bvar, d + h.host_bytes + align_up(tb, 256), L.total - L.o_bvar,
+                            hipMemcpyDeviceToDevice, c.stream));
+    HIPCHECK(hipStreamSynchronize(c.stream));
+    rebuild_pos(dst);
+    dst->valid = true;
+  }
+  return 0;
+}
+
 void tuning(int tr, int hot, int nt) {
   sync_stream();
   set_tuning(tr, hot, nt);

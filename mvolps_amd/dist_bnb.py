@@ -1,0 +1,327 @@
+"""Multi-GPU branch-and-bound: node LPs farmed over the ranks of one node, serial-equivalent.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the
+CPU tests).  What is sharded is the unit the reference itself treats as independent: one B&B node
+= one `glp_prob` clone + its `glp_simplex` calls (/root/reference/bs.cpp:114-117,269-288).  The only
+shared state is the incumbent `bestLower` (bs.cpp:90,172-174) and the child bounds
+(`NodeData::upperBound`, bs.cpp:280,288); both travel in small MAX all-reduces.
+
+Serial equivalence.  With the reference's default FIFO node order
+(`problems.front()`, util.cpp:165-166) children go to the back of the deque (bs.cpp:297-298) and no
+node is discarded before it has been solved, so the next W nodes the serial loop would pop are
+exactly the front W of the deque whatever their outcome.  Each round therefore
+  A. solves the front window in parallel (owner ranks), MAX-all-reduces (status, objective, ...);
+  B. replays the serial decisions in queue order on every rank (incumbent updated in that order),
+     which fixes the branch list and the child oids;
+  C. lets the owners create and solve the children (bs.cpp:269-288), MAX-all-reduces their bounds;
+  D. deals the children round-robin over the ranks; a child that lands on another rank is
+     migrated as a device image of its bounds + basis + tableau (mvx_pack / mvx_unpack) by an
+     RCCL send/recv -- a bitwise copy, so its later arithmetic is the serial run's.
+Tree, oids, prune labels, events and the incumbent come out identical to the serial driver
+(mvx_branchAndBound); tests/test_dist_bnb.py asserts that with world_size 2.
+
+Best-bound order (util.cpp:170-186) picks by fresh child bounds and is not window-batchable; GMI
+cut rows are not carried by migration.  Both stay on the single-GPU driver.
+"""
+import math
+from collections import deque
+
+import numpy as np
+import torch
+
+from . import capi
+
+NEG_INF = float("-inf")
+EV_PREGNANT, EV_INTEGER, EV_INFEASIBLE, EV_FATHOMED, EV_BRANCHED, EV_CANDIDATE = range(6)
+INTG, FEAS, BNDS, NONE = 0, 1, 3, 4
+
+
+def get_fract(x):
+    """util.cpp:11-23"""
+    f, _ = math.modf(x)
+    if f < 0.0:
+        f += 1
+    return f
+
+
+def branch_direction(oid):
+    """bs.cpp:43-52"""
+    if oid <= 1:
+        return 0
+    return 1 if oid % 2 == 0 else 2
+
+
+class HipNodeEngine:
+    """The gfx950 engine as seen by the coordinator: handles, printInfo, and migration images that
+    live in device memory (torch CUDA tensors) so that RCCL moves them GPU to GPU."""
+
+    def __init__(self, local_rank=0, comm_device=None):
+        import mvolps_amd
+        from . import bnb
+
+        mvolps_amd.require_device()
+        self.api = mvolps_amd.api()
+        if self.api.set_device(local_rank) != 0:
+            raise RuntimeError("cannot bind device %d" % local_rank)
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        # tensors handed to the process group: on the GPU for RCCL, on the host for gloo
+        self.comm_device = torch.device(comm_device) if comm_device else self.device
+        self._bnb = bnb
+        self.table = None
+
+    def print_info(self, prob, quirks):
+        return self._bnb.print_info(prob, quirks=quirks, table=self.table)
+
+    def pack(self, prob):
+        n = self.api.pack_size(prob.h)
+        t = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if self.api.pack(prob.h, t.data_ptr()) != 0:
+            raise RuntimeError("mvx_pack failed")
+        return t.to(self.comm_device)
+
+    def recv_buffer(self, nbytes):
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.comm_device)
+
+    def unpack(self, base, t):
+        t = t.to(self.device)
+        torch.cuda.synchronize()
+        q = self.api.create()
+        if self.api.unpack(q.h, base.h, t.data_ptr()) != 0:
+            raise RuntimeError("mvx_unpack failed")
+        return q
+
+
+class _Node:
+    __slots__ = ("oid", "owner", "upper", "inital")
+
+    def __init__(self, oid, owner, upper, inital=False):
+        self.oid, self.owner, self.upper, self.inital = oid, owner, upper, inital
+
+
+def _pick_var(api, root, vars_, strat):
+    """ParameterObj::pickVar, util.cpp:190-230 (queries the never-solved ROOT problem)."""
+    if strat == 0:
+        return vars_[0]
+    if strat == 1:
+        cur_best = abs(get_fract(api.get_col_prim(root.h, vars_[0])) - 0.5)
+        index = vars_[0]
+        for i in vars_:
+            cur = abs(get_fract(api.get_col_prim(root.h, i)) - 0.5)
+            if cur < cur_best:
+                cur_best, index = cur, i
+        return index
+    best, index = 0.0, vars_[0]
+    for i in vars_:
+        cur = api.get_obj_coef(root.h, i)
+        if cur > best:
+            best, index = cur, i
+    return index
+
+
+def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limit=200000, per_rank=1, group=None):
+    """Serial-equivalent FIFO branch-and-bound over all ranks of `group`.
+
+    `root` is this rank's handle of the (identical) root problem.  Returns the same dictionary as
+    mvolps_amd.bnb.branch_and_bound, identical on every rank.
+    """
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    api = engine.api
+    cdev = engine.comm_device
+
+    def allreduce_max(t):
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return t.cpu().numpy()
+
+    parent, prune, bound = {1: 0}, {1: NONE}, {1: float("inf")}
+    events = []
+    queue = deque([_Node(1, 0, float("inf"), True)])
+    local = {}
+    if rank == 0:
+        local[1] = root.copy(capi.ON)  # S1 = NodeData(prob), bs.cpp:80
+    next_id = 2
+    child_seq = 0
+    best_lower, has_inc, inc_oid, inc_owner = NEG_INF, 0, 0, 0
+    x_keep = {}
+    count, hit_limit, total_pivots = 0, 0, 0
+    n0 = root.n
+    stop_all = False
+
+    while queue and not stop_all:
+        if max_nodes > 0 and count >= max_nodes:
+            hit_limit = 1
+            break
+        W = min(len(queue), world * per_rank)
+        window = [queue[i] for i in range(W)]
+
+        # ---- A. solve the window (bs.cpp:114-117, printInfo bs.cpp:135|151)
+        A = torch.full((W, 6), NEG_INF, dtype=torch.float64)
+        solved = {}
+        for w, nd in enumerate(window):
+            if nd.owner != rank:
+                continue
+            a = api.create()
+            api.copy_prob(a.h, local[nd.oid].h, capi.OFF)
+            before = a.it_cnt
+            a.simplex()
+            st, viol = engine.print_info(a, quirks)
+            acc = 0.0
+            for i in viol:
+                if i != 0:
+                    acc += get_fract(api.get_col_prim(a.h, i))
+            pick = _pick_var(api, root, viol, var_strat) if viol else 0
+            A[w] = torch.tensor([float(st), a.obj, float(len(viol)), acc, float(pick), float(a.it_cnt - before)], dtype=torch.float64)
+            solved[nd.oid] = a
+            if st == 1:
+                x_keep[nd.oid] = a.col_prim()
+        A = allreduce_max(A.to(cdev))
+
+        # ---- B. replay the serial decisions in queue order
+        per_node_events = []
+        branch_list = []
+        processed = 0
+        for w, nd in enumerate(window):
+            if max_nodes > 0 and count >= max_nodes:
+                hit_limit = 1
+                stop_all = True
+                break
+            st, obj, nv, acc, pick, piv = int(A[w][0]), float(A[w][1]), int(A[w][2]), float(A[w][3]), int(A[w][4]), int(A[w][5])
+            total_pivots += piv
+            ev = [(EV_PREGNANT, nd.oid, obj, 0.0, 0, 0)]
+            per_node_events.append(ev)
+            processed += 1
+            if nd.inital:
+                if st == -1:  # bs.cpp:139-143
+                    prune[nd.oid] = FEAS
+                    stop_all = True
+                    break
+                if st == 1:  # bs.cpp:144-149
+                    nd.upper = obj
+                    bound[nd.oid] = obj
+                    prune[nd.oid] = INTG
+                    stop_all = True
+                    break
+            nd.upper = obj
+            bound[nd.oid] = obj
+            if st == 1:
+                prune[nd.oid] = INTG
+                ev.append((EV_INTEGER, nd.oid, obj, 0.0, 0, 0))
+                if obj > best_lower:
+                    best_lower, has_inc, inc_oid, inc_owner = obj, 1, nd.oid, nd.owner
+            elif st == -1:
+                prune[nd.oid] = FEAS
+                ev.append((EV_INFEASIBLE, nd.oid, 0.0, 0.0, 0, 0))
+            elif obj <= best_lower:
+                prune[nd.oid] = BNDS
+                ev.append((EV_FATHOMED, nd.oid, 0.0, 0.0, 0, 0))
+            else:
+                s2, s3 = next_id, next_id + 1
+                next_id += 2
+                for c in (s2, s3):
+                    parent[c], prune[c], bound[c] = nd.oid, NONE, float("inf")
+                ev.append((EV_BRANCHED, nd.oid, obj, acc, nv, pick))
+                branch_list.append((nd, s2, s3, pick, ev))
+                if count > loop_limit:  # bs.cpp:320-323
+                    hit_limit = 1
+                    count += 1
+                    stop_all = True
+                    break
+            count += 1
+
+        # ---- C. owners create and solve the children (bs.cpp:269-288)
+        C = torch.full((max(1, len(branch_list)), 4), NEG_INF, dtype=torch.float64)
+        fresh = {}
+        for k, (nd, s2, s3, pick, ev) in enumerate(branch_list):
+            if nd.owner != rank:
+                continue
+            a = solved[nd.oid]
+            bnd = api.get_col_prim(a.h, pick)  # bs.cpp:261
+            S2, S3 = a.copy(capi.ON), a.copy(capi.ON)
+            if quirks:
+                api.set_col_bnds(S2.h, pick, capi.UP, 0.0, math.floor(bnd))  # bs.cpp:274
+            else:
+                t, l = api.get_col_type(a.h, pick), api.get_col_lb(a.h, pick)
+                if t in (capi.LO, capi.DB, capi.FX):
+                    api.set_col_bnds(S2.h, pick, capi.FX if l == math.floor(bnd) else capi.DB, l, math.floor(bnd))
+                else:
+                    api.set_col_bnds(S2.h, pick, capi.UP, 0.0, math.floor(bnd))
+            b2 = S2.it_cnt
+            S2.simplex()  # bs.cpp:279
+            if quirks:
+                api.set_col_bnds(S3.h, pick, capi.LO, math.ceil(bnd), 0.0)  # bs.cpp:282
+            else:
+                t, u = api.get_col_type(a.h, pick), api.get_col_ub(a.h, pick)
+                if t in (capi.UP, capi.DB, capi.FX):
+                    api.set_col_bnds(S3.h, pick, capi.FX if u == math.ceil(bnd) else capi.DB, math.ceil(bnd), u)
+                else:
+                    api.set_col_bnds(S3.h, pick, capi.LO, math.ceil(bnd), 0.0)
+            b3 = S3.it_cnt
+            S3.simplex()  # bs.cpp:287
+            C[k] = torch.tensor([S2.obj, S3.obj, float((S2.it_cnt - b2) + (S3.it_cnt - b3)), float(api.pack_size(S2.h))], dtype=torch.float64)
+            fresh[s2], fresh[s3] = S2, S3
+        C = allreduce_max(C.to(cdev))
+
+        # ---- D. publish the children, deal them round-robin, migrate where needed
+        sends, recvs = [], []
+        for k, (nd, s2, s3, pick, ev) in enumerate(branch_list):
+            ub2, ub3, piv, nbytes = float(C[k][0]), float(C[k][1]), int(C[k][2]), int(C[k][3])
+            total_pivots += piv
+            for oid, ub in ((s2, ub2), (s3, ub3)):
+                owner = child_seq % world
+                child_seq += 1
+                bound[oid] = ub
+                queue.append(_Node(oid, owner, ub))
+                ev.append((EV_CANDIDATE, oid, ub, 0.0, 0, 0))
+                if nd.owner == rank and owner == rank:
+                    local[oid] = fresh[oid]
+                elif nd.owner == rank:
+                    sends.append((oid, owner, engine.pack(fresh[oid])))
+                elif owner == rank:
+                    recvs.append((oid, nd.owner, engine.recv_buffer(nbytes)))
+        if world > 1 and (sends or recvs):
+            ops = [dist.P2POp(dist.isend, t, dst, group=group) for (_, dst, t) in sends]
+            ops += [dist.P2POp(dist.irecv, t, src, group=group) for (_, src, t) in recvs]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            for oid, _, t in recvs:
+                local[oid] = engine.unpack(root, t)
+        for ev in per_node_events:
+            events.extend(ev)
+        for _ in range(processed):
+            nd = queue.popleft()
+            local.pop(nd.oid, None)
+        solved.clear()
+        for oid in list(x_keep):
+            if oid != inc_oid:
+                del x_keep[oid]
+
+    # incumbent solution (bs.cpp:181-187) from the rank that solved it
+    x = torch.zeros(n0, dtype=torch.float64)
+    if has_inc and rank == inc_owner:
+        x = torch.from_numpy(np.ascontiguousarray(x_keep[inc_oid][:n0]))
+    if world > 1 and has_inc:
+        xt = x.to(cdev)
+        dist.broadcast(xt, src=inc_owner if group is None else dist.get_global_rank(group, inc_owner), group=group)
+        x = xt.cpu()
+    nn = next_id - 1
+    out_events = [(t, oid, parent[oid], branch_direction(oid), f6, f7, f8, pk) for (t, oid, f6, f7, f8, pk) in events]
+    return {
+        "n_nodes": nn,
+        "parent": [parent[i] for i in range(1, nn + 1)],
+        "prune": [prune[i] for i in range(1, nn + 1)],
+        "node_bound": [bound[i] for i in range(1, nn + 1)],
+        "events": out_events,
+        "count": count,
+        "has_incumbent": has_inc,
+        "best_lower": best_lower,
+        "incumbent_oid": inc_oid,
+        "x": [float(v) for v in x.tolist()],
+        "total_pivots": total_pivots,
+        "hit_limit": hit_limit,
+    }

@@ -953,3 +953,79 @@ int orc_get_basis(const orc_prob *P, int *head, int *nb, int *flag) {
   }
   return 0;
 }
+
+/* ------------------------------------------------------------- pack / unpack */
+typedef struct {
+  long long magic, m, n, ld, status, it_cnt, valid, reserved;
+} pack_hdr;
+#define PACK_MAGIC 0x4d56584f5243ll
+
+long long orc_pack_size(const orc_prob *P) {
+  long long m = P->m, n = P->n;
+  long long sz = sizeof(pack_hdr);
+  sz += (long long)sizeof(int) * ((n + 1) + (m + 1) + (m + 1) + 2 * (n + 1));
+  sz = (sz + 7) / 8 * 8;
+  sz += (long long)sizeof(double) * (2 * (n + 1) + 2 * (m + 1));
+  if (P->valid) sz += (long long)sizeof(double) * ((m + 1) * (long long)P->ld + 2 * (m + 1) + 2 * (n + 1));
+  return sz;
+}
+
+int orc_pack(const orc_prob *P, void *buf) {
+  int m = P->m, n = P->n;
+  unsigned char *b = (unsigned char *)buf;
+  pack_hdr h = {PACK_MAGIC, m, n, P->ld, P->status, P->it_cnt, P->valid, 0};
+  memcpy(b, &h, sizeof(h)); b += sizeof(h);
+  unsigned char *b0 = b;
+#define PUT(ptr, cnt, T) do { memcpy(b, (ptr), (size_t)(cnt) * sizeof(T)); b += (size_t)(cnt) * sizeof(T); } while (0)
+  PUT(P->ctype, n + 1, int);
+  PUT(P->rtype, m + 1, int);
+  if (P->valid) { PUT(P->bvar, m + 1, int); PUT(P->nvar, n + 1, int); PUT(P->nflag, n + 1, int); }
+  else b += sizeof(int) * ((size_t)(m + 1) + 2 * (size_t)(n + 1));
+  b = b0 + ((size_t)(b - b0) + 7) / 8 * 8;
+  PUT(P->clb, n + 1, double); PUT(P->cub, n + 1, double);
+  PUT(P->rlb, m + 1, double); PUT(P->rub, m + 1, double);
+  if (P->valid) {
+    PUT(P->T, (size_t)(m + 1) * P->ld, double);
+    PUT(P->blb, m + 1, double); PUT(P->bub, m + 1, double);
+    PUT(P->nlb, n + 1, double); PUT(P->nub, n + 1, double);
+  }
+#undef PUT
+  return 0;
+}
+
+int orc_unpack(orc_prob *dst, const orc_prob *base, const void *buf) {
+  const unsigned char *b = (const unsigned char *)buf;
+  pack_hdr h;
+  memcpy(&h, b, sizeof(h)); b += sizeof(h);
+  if (h.magic != PACK_MAGIC || h.m != base->m || h.n != base->n) return -1;
+  int m = (int)h.m, n = (int)h.n;
+  /* model rows / objective / kinds come from the receiver's copy of the root problem */
+  {
+    int was_valid = base->valid;
+    ((orc_prob *)base)->valid = 0; /* copy the model only */
+    orc_copy_prob(dst, base, ORC_ON);
+    ((orc_prob *)base)->valid = was_valid;
+  }
+  const unsigned char *b0 = b;
+#define GET(ptr, cnt, T) do { memcpy((ptr), b, (size_t)(cnt) * sizeof(T)); b += (size_t)(cnt) * sizeof(T); } while (0)
+  GET(dst->ctype, n + 1, int);
+  GET(dst->rtype, m + 1, int);
+  if (h.valid) { GET(dst->bvar, m + 1, int); GET(dst->nvar, n + 1, int); GET(dst->nflag, n + 1, int); }
+  else b += sizeof(int) * ((size_t)(m + 1) + 2 * (size_t)(n + 1));
+  b = b0 + ((size_t)(b - b0) + 7) / 8 * 8;
+  GET(dst->clb, n + 1, double); GET(dst->cub, n + 1, double);
+  GET(dst->rlb, m + 1, double); GET(dst->rub, m + 1, double);
+  dst->status = (int)h.status;
+  dst->it_cnt = (int)h.it_cnt;
+  dst->valid = (int)h.valid;
+  if (h.valid) {
+    dst->ld = (int)h.ld;
+    free(dst->T);
+    dst->T = (double *)xcalloc((size_t)(dst->m_cap + 1) * dst->ld, sizeof(double));
+    GET(dst->T, (size_t)(m + 1) * dst->ld, double);
+    GET(dst->blb, m + 1, double); GET(dst->bub, m + 1, double);
+    GET(dst->nlb, n + 1, double); GET(dst->nub, n + 1, double);
+  }
+#undef GET
+  return 0;
+}

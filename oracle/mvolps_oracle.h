@@ -128,6 +128,12 @@ int orc_get_tableau(const orc_prob *P, double *out);
    flag[0..n] non-basic status (ORC_NL/NU/NF/NS) */
 int orc_get_basis(const orc_prob *P, int *head, int *nb, int *flag);
 
+/* node migration between ranks: serialise bounds + basis + tableau of P (same model rows as
+   the receiver's base problem; appended cut rows are not carried).  Host memory. */
+long long orc_pack_size(const orc_prob *P);
+int orc_pack(const orc_prob *P, void *buf);
+int orc_unpack(orc_prob *dst, const orc_prob *base, const void *buf);
+
 /* ---- MVOLPS-owned pieces restated on top of the API above ---- */
 double orc_getFract(double x); /* util.cpp:11-23 */
 

@@ -1,0 +1,77 @@
+"""Test-side adapters for the distributed coordinator (tests only: this is where the ORACLE is plugged in)."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleNodeEngine:
+    """CPU stand-in for HipNodeEngine built on the oracle library; migration images are host tensors."""
+
+    def __init__(self):
+        from mvolps_amd import bnb
+        from oracle import oracle
+
+        self.api = oracle.api()
+        self.table = bnb.table_from(self.api)
+        self._bnb = bnb
+        self.comm_device = torch.device("cpu")
+
+    def print_info(self, prob, quirks):
+        return self._bnb.print_info(prob, quirks=quirks, table=self.table)
+
+    def pack(self, prob):
+        n = self.api.pack_size(prob.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        assert self.api.pack(prob.h, buf.ctypes.data) == 0
+        return torch.from_numpy(buf)
+
+    def recv_buffer(self, nbytes):
+        return torch.empty(nbytes, dtype=torch.uint8)
+
+    def unpack(self, base, t):
+        buf = np.ascontiguousarray(t.numpy())
+        q = self.api.create()
+        assert self.api.unpack(q.h, base.h, buf.ctypes.data) == 0
+        return q
+
+
+def _worker(rank, world, port, outdir, case, kw, use_gpu):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import torch.distributed as dist
+
+    from mvolps_amd import dist_bnb, synth
+    from tests import lpgen
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        if use_gpu:
+            eng = dist_bnb.HipNodeEngine(0, comm_device="cpu")  # both ranks share cuda:0; gloo moves host copies
+        else:
+            eng = OracleNodeEngine()
+        m, n, seed, U = case
+        A, b, c, U = synth.dense_ilp(m, n, seed, U)
+        root = lpgen.load_ilp(eng.api, A, b, c, U)
+        res = dist_bnb.branch_and_bound(eng, root, **kw)
+        with open(os.path.join(outdir, "rank%d.json" % rank), "w") as f:
+            json.dump(res, f)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_world(world, case, kw, outdir, use_gpu=False, port=None):
+    import torch.multiprocessing as mp
+
+    port = port or (29500 + (os.getpid() % 2000))
+    mp.spawn(_worker, args=(world, port, outdir, case, kw, use_gpu), nprocs=world, join=True)
+    return [json.load(open(os.path.join(outdir, "rank%d.json" % r))) for r in range(world)]
