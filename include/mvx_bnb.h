@@ -112,6 +112,20 @@ int mvx_printInfo(const mvx_lp_api *api, const void *prob, int quirks, int *viol
 /* CutContainer generateCut3(glp_prob*, int j)  gmi.h:7; inds/vals hold n+1 entries, returns -1 when rejected */
 int mvx_generateCut3(const mvx_lp_api *api, const void *prob, int j, int *inds, double *vals, double *lb);
 
+/* ---- callers and data formats either side of the path ---- */
+/* glp_read_lp(prob, NULL, fname) util.cpp:284 -- CPLEX LP format; 0 on success */
+int mvx_read_lp(mvx_prob *P, const void *parm, const char *fname);
+/* glp_read_mps(prob, GLP_MPS_FILE, NULL, fname) util.cpp:290 -- free/fixed MPS; 0 on success */
+int mvx_read_mps(mvx_prob *P, int fmt, const void *parm, const char *fname);
+/* the B&B event stream of IPCDispatch::write (message.cpp:32-191), one text line per event in the
+   format of message.h:141-226, to `path` (NULL = stdout) instead of a ZeroMQ socket; the first field
+   (timeSpan) is the event's sequence number so that two runs can be diffed */
+int mvx_bnb_write_events(const mvx_bnb_result *res, const char *path);
+/* the tree report of bs.cpp:329-343 (PrettyPrintTree, tree_print.h:12-22) */
+int mvx_bnb_print_tree(const mvx_bnb_result *res, const char *path);
+/* the solution line of bs.cpp:176-191; returns 0, or the needed capacity when `cap` is too small */
+int mvx_bnb_solution_string(const mvx_lp_api *api, const void *root, const mvx_bnb_result *res, char *buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmvolps_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp", "bnb.cpp"]
+SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp", "bnb.cpp", "io.cpp"]
+BINDIR = os.path.join(HERE, "bin")
+CLI = os.path.join(BINDIR, "mvolps")
 # -ffp-contract=off: fma() only where written, on host and device alike (bit-exact parity
 # with the CPU oracle)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-math-errno", "-Wall",
@@ -39,6 +41,14 @@ def build(force=False, verbose=False):
         objs.append(op)
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    # command-line front end (the counterpart of 2test.cpp's main)
+    os.makedirs(BINDIR, exist_ok=True)
+    main_src = os.path.join(CSRC, "mvolps_main.cpp")
+    if force or _stale(CLI, [main_src, LIB] + hdrs):
+        cmd = [HIPCC, "-O2", "-std=c++17", main_src, "-o", CLI, "-L" + LIBDIR, "-lmvolps_amd", "-Wl,-rpath,$ORIGIN/../lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -593,84 +593,133 @@ __global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
   }
 }
 
+// wave-level arg-best over values already in registers, broadcast to all lanes
+template <int MODE>
+__device__ __forceinline__ Cand wave_bcast_best(Cand b) {
+  b = wave_best<MODE>(b);
+  Cand r;
+  r.k1 = __shfl(b.k1, 0, 64);
+  r.k2 = __shfl(b.k2, 0, 64);
+  r.idx = __shfl(b.idx, 0, 64);
+  r.aux = __shfl(b.aux, 0, 64);
+  return r;
+}
+
+// Three dependent memory levels only: (1) the control block, (2) partials + this lane's own
+// objective-row entry, (3) what depends on the chosen q / p.  Loads of one level are issued
+// together, before the first use.
 __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
   __shared__ Cand lds[17];
-  if (c->done != D_RUN || c->fstate != F_RUN) return;
-  const int cur = c->curA;
-  const bool lead = (blockIdx.x == 0 && TIDX == 0);
-  // entering column
-  Cand pc = wave_reduce_partials<0>(c->pp[cur], c->npb);
-  if (pc.idx == 0 || c->budget == 0) {
-    if (lead) c->fstate = F_STOP;
-    return;
-  }
-  const int q = pc.idx, sdir = pc.aux;
-  // leaving row
-  Cand rc = wave_reduce_partials<1>(c->rp, c->nrb);
-  const double lbq = c->nlb[q], ubq = c->nub[q];
-  const int fq = c->nflag[q];
-  const int n = c->n;
-  const int j = (int)blockIdx.x * 256 + TIDX;
+  // level 1
+  const int done = c->done, fstate = c->fstate, cur = c->curA, budget = c->budget;
+  const int npb = c->npb, nrb = c->nrb, n = c->n, ldi = c->ld;
+  double *const T = c->T;
+  double *const srow = c->srow;
+  const int *const nflag = c->nflag;
+  const double *const nlb = c->nlb, *const nub = c->nub, *const blb = c->blb, *const bub = c->bub;
+  const double *const colq = c->colqx[cur];
+  const Cand *const pp = c->pp[cur];
+  Cand *const ppn = c->pp[cur ^ 1];
+  const Cand *const rp = c->rp;
   const double tol = c->tol_dj, sgn = c->sgn;
-  Cand best{0.0, 0.0, 0, 0};
-  if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
-    const double tf = ubq - lbq;
-    if (rc.idx == 0 || tf <= rc.k1) {
-      // bound flip: tableau body and objective row unchanged; column q changes status
-      const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
-      if (j >= 1 && j <= n) {
-        Cand x;
-        if (price_col(j == q ? nf : c->nflag[j], sgn * c->T[j], tol, j, x)) best = x;
-      }
-      best = block_best<0>(best, lds);
-      if (TIDX == 0) c->pp[cur ^ 1][blockIdx.x] = best;
-      if (lead) {
-        c->step = ST_FLIP;
-        c->q = q;
-        c->sdir = sdir;
-        c->delta = (sdir > 0) ? tf : -tf;
-        c->flipflag = nf;
-        c->curB = cur;
-      }
+  if (done != D_RUN || fstate != F_RUN) return;
+  const bool lead = (blockIdx.x == 0 && TIDX == 0);
+  const int lane = TIDX & 63;
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  const bool act = (j <= n);
+  // level 2
+  Cand pc = (lane < npb) ? pp[lane] : Cand{0.0, 0.0, 0, 0};
+  Cand rc{0.0, 0.0, 0, 0};
+  {
+    Cand r0 = (lane < nrb) ? rp[lane] : Cand{0.0, 0.0, 0, 0};
+    Cand r1 = (lane + 64 < nrb) ? rp[lane + 64] : Cand{0.0, 0.0, 0, 0};
+    Cand r2 = (lane + 128 < nrb) ? rp[lane + 128] : Cand{0.0, 0.0, 0, 0};
+    Cand r3 = (lane + 192 < nrb) ? rp[lane + 192] : Cand{0.0, 0.0, 0, 0};
+    const double dold_ = act ? T[j] : 0.0;
+    const int fj_ = (act && j >= 1) ? nflag[j] : MVX_NS;
+    for (int k = lane + 64; k < npb; k += 64) {
+      Cand x = pp[k];
+      if (cand_better<0>(x, pc)) pc = x;
+    }
+    rc = r0;
+    if (cand_better<1>(r1, rc)) rc = r1;
+    if (cand_better<1>(r2, rc)) rc = r2;
+    if (cand_better<1>(r3, rc)) rc = r3;
+    for (int k = lane + 256; k < nrb; k += 64) {
+      Cand x = rp[k];
+      if (cand_better<1>(x, rc)) rc = x;
+    }
+    pc = wave_bcast_best<0>(pc);
+    rc = wave_bcast_best<1>(rc);
+    // entering column
+    if (pc.idx == 0 || budget == 0) {
+      if (lead) c->fstate = F_STOP;
       return;
     }
-  }
-  if (rc.idx == 0) {
-    if (lead) c->fstate = F_STOP; // unbounded ray: the generic path reports it
-    return;
-  }
-  const int p = rc.idx, p_up = rc.aux;
-  const double piv = c->colqx[cur][p];
-  const double bound = p_up ? c->bub[p] : c->blb[p];
-  const double dq = c->colqx[cur][0];
-  const int lf = dev_leave_flag(c->blb[p], c->bub[p], p_up);
-  if (j <= n) {
-    const double v = c->T[(size_t)p * c->ld + j];
-    const double s = (j == 0) ? (v - bound) / piv : v / piv;
-    c->srow[j] = s;
-    const double dold = c->T[j];
-    const double dnew = (j == q) ? dq / piv : fma(-dq, s, dold);
-    c->T[j] = dnew;
-    if (j >= 1) {
-      Cand x;
-      if (price_col(j == q ? lf : c->nflag[j], sgn * dnew, tol, j, x)) best = x;
+    const int q = pc.idx, sdir = pc.aux;
+    const int p = rc.idx, p_up = rc.aux; // p == 0: no blocking row
+    // level 3
+    const double lbq = nlb[q], ubq = nub[q];
+    const int fq = nflag[q];
+    const int pr = p ? p : 1;
+    const double piv = colq[pr], dq = colq[0];
+    const double plb = blb[pr], pub = bub[pr];
+    const double v = act ? T[(size_t)pr * ldi + j] : 0.0;
+    Cand best{0.0, 0.0, 0, 0};
+    if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+      const double tf = ubq - lbq;
+      if (p == 0 || tf <= rc.k1) {
+        // bound flip: tableau body and objective row unchanged; column q changes status
+        const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
+        if (act && j >= 1) {
+          Cand x;
+          if (price_col(j == q ? nf : fj_, sgn * dold_, tol, j, x)) best = x;
+        }
+        best = block_best<0>(best, lds);
+        if (TIDX == 0) ppn[blockIdx.x] = best;
+        if (lead) {
+          c->step = ST_FLIP;
+          c->q = q;
+          c->sdir = sdir;
+          c->delta = (sdir > 0) ? tf : -tf;
+          c->flipflag = nf;
+          c->curB = cur;
+        }
+        return;
+      }
     }
-  }
-  best = block_best<0>(best, lds);
-  if (TIDX == 0) c->pp[cur ^ 1][blockIdx.x] = best;
-  if (lead) {
-    c->step = ST_PIVOT;
-    c->p = p;
-    c->q = q;
-    c->sdir = sdir;
-    c->p_up = p_up;
-    c->piv = piv;
-    c->bound = bound;
-    c->xq = dev_nb_value(fq, lbq, ubq);
-    c->leave_flag = lf;
-    c->ent_lb = lbq;
-    c->ent_ub = ubq;
-    c->curB = cur;
+    if (p == 0) {
+      if (lead) c->fstate = F_STOP; // unbounded ray: the generic path reports it
+      return;
+    }
+    const double bound = p_up ? pub : plb;
+    const int lf = dev_leave_flag(plb, pub, p_up);
+    if (act) {
+      const double sj = (j == 0) ? (v - bound) / piv : v / piv;
+      srow[j] = sj;
+      const double dnew = (j == q) ? dq / piv : fma(-dq, sj, dold_);
+      T[j] = dnew;
+      if (j >= 1) {
+        Cand x;
+        if (price_col(j == q ? lf : fj_, sgn * dnew, tol, j, x)) best = x;
+      }
+    }
+    best = block_best<0>(best, lds);
+    if (TIDX == 0) ppn[blockIdx.x] = best;
+    if (lead) {
+      c->step = ST_PIVOT;
+      c->p = p;
+      c->q = q;
+      c->sdir = sdir;
+      c->p_up = p_up;
+      c->piv = piv;
+      c->bound = bound;
+      c->xq = dev_nb_value(fq, lbq, ubq);
+      c->leave_flag = lf;
+      c->ent_lb = lbq;
+      c->ent_ub = ubq;
+      c->curB = cur;
+    }
   }
 }
 
@@ -712,6 +761,10 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   const bool tile0 = (blockIdx.x == 0);
   const double *colq = c->colqx[cur];
   double *bnew = c->betac[nxt];
+  // pricing partial of the NEXT step: requested now, reduced after the stream has been issued
+  const int npb = c->npb;
+  const Cand *ppn = c->pp[nxt];
+  Cand ncv = ((TIDX & 63) < npb) ? ppn[TIDX & 63] : Cand{0.0, 0.0, 0, 0};
   if (step == ST_PIVOT) {
     if (active) {
       const double2 s = *reinterpret_cast<const double2 *>(c->srow + j0);
@@ -791,7 +844,11 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
     bnew[i] = beta;
   }
   // next entering column (0 = none: k_fa will stop); reduced after the stream has been issued
-  const Cand nc = wave_reduce_partials<0>(c->pp[nxt], c->npb);
+  for (int k = (TIDX & 63) + 64; k < npb; k += 64) {
+    Cand x = ppn[k];
+    if (cand_better<0>(x, ncv)) ncv = x;
+  }
+  const Cand nc = wave_bcast_best<0>(ncv);
   const int qn = nc.idx, sdn = nc.aux;
   const bool tilen = (qn != 0 && (qn >> 9) == (int)blockIdx.x); // 512 columns per tile
   if (tilen) {

@@ -73,3 +73,21 @@ def test_config3_ilp_512x1024_first_nodes(gpu, orc):
     got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), max_nodes=6)
     same_result(got, ref)
     assert got["total_pivots"] > 100
+
+
+def test_cli_end_to_end_f1(gpu, tmp_path):
+    """Config 1 plumbing: `mvolps -f f1.lp` (2test.cpp main) -> reader -> B&B on the GPU -> tree + solution."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "mvolps_amd", "bin", "mvolps")
+    for ext in ("lp", "mps"):
+        ev = tmp_path / ("ev_%s.txt" % ext)
+        r = subprocess.run([exe, "-f", os.path.join(root, "tests", "golden", "f1." + ext), "--repaired", "-v", "--events", str(ev)],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "[I = Integral node, F = Infeasible node, B = Worse bound node]" in r.stdout
+        assert "Solution is: 3*(x[3] = 7) + 7*(x[4] = 2) + 0 = 35" in r.stdout
+        assert open(ev).read().splitlines()[-1] == "END"
+    r = subprocess.run([exe, "-f", "nope.txt"], capture_output=True, text=True)
+    assert "Unrecognized filetype" in r.stdout

@@ -1,0 +1,82 @@
+"""GPU: edge cases of the engine's bookkeeping paths (row-capacity growth, zero-pivot limits, tiny and
+ragged shapes, repeated clone/free cycles through the slab cache)."""
+import numpy as np
+import pytest
+
+from mvolps_amd import capi, synth
+from mvolps_amd.capi import LO, UP
+
+from . import lpgen
+
+pytestmark = pytest.mark.gpu
+
+
+def test_many_appended_rows_grow_the_slab(gpu, orc):
+    """More cut rows than the spare capacity: the slab is re-allocated and copied (grow_rows)."""
+    A, b, c, U = synth.dense_ilp(12, 24, 7, 3)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    rng = np.random.default_rng(11)
+    n = 24
+    ind = np.arange(n + 1, dtype=np.int32)
+    for k in range(80):
+        v = np.round(rng.normal(size=n) * 2)
+        x = o.col_prim()
+        lb = float(v @ x) - (0.0 if k % 3 else -0.25)
+        for P in (g, o):
+            r = P.api.add_rows(P.h, 1)
+            P.set_mat_row(r, ind, np.concatenate([[0.0], v]))
+            P.api.set_row_bnds(P.h, r, LO, lb, 0.0)
+            P.simplex()
+        assert g.status == o.status and g.it_cnt == o.it_cnt, k
+        assert np.array_equal(g.tableau(), o.tableau()), k
+    assert g.m == 12 + 80
+
+
+def test_zero_iteration_limit(gpu, orc):
+    A, b, c = synth.dense_lp(30, 50, 4)
+    for api in (gpu, orc):
+        P = api.create()
+        P.load_dense(A, b, c)
+        assert P.simplex(it_lim=0) == capi.EITLIM
+        assert P.it_cnt == 0 and P.status == capi.FEAS
+        assert P.obj == 0.0
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 7), (9, 1), (2, 511), (33, 513), (257, 31)])
+def test_ragged_shapes(gpu, orc, m, n):
+    A, b, c = synth.dense_lp(m, n, 100 + m + n)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+        P.simplex()
+    assert g.status == o.status and g.it_cnt == o.it_cnt
+    assert np.array_equal(g.tableau(), o.tableau())
+
+
+def test_empty_problem_is_rejected(gpu, orc):
+    for api in (gpu, orc):
+        P = api.create()
+        assert P.simplex() == capi.EFAIL and P.status == capi.UNDEF
+
+
+def test_clone_free_cycles_reuse_slabs(gpu, orc):
+    A, b, c, U = synth.dense_ilp(16, 32, 5, 2)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        P.simplex()
+    x = o.col_prim()
+    frac = [j + 1 for j in range(32) if np.trunc(x[j]) != x[j]]
+    for rep in range(50):
+        j = frac[rep % len(frac)]
+        res = []
+        for P in (g, o):
+            ch = P.copy()
+            P.api.set_col_bnds(ch.h, j, UP, 0.0, float(np.floor(x[j - 1])) - (rep % 2))
+            ch.simplex()
+            res.append((ch.status, ch.it_cnt, ch.tableau()))
+            del ch
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
