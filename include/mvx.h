@@ -91,6 +91,12 @@ void mvx_init_smcp(mvx_smcp *parm);                /* glp_init_smcp */
 int mvx_simplex(mvx_prob *P, const mvx_smcp *parm); /* glp_simplex bs.cpp:117,279,287;
                                                        BranchAndBound.cpp:52,134,141 */
 
+/* batch entry (SURVEY.md section 8(b) "a batch entry for config 5"): `count` independent handles --
+   e.g. the two children of a branch (bs.cpp:279,287) or a window of open nodes -- solved
+   concurrently, one HIP stream each; results are identical to `count` calls of mvx_simplex.
+   rcs[i] (nullable) receives each handle's return code */
+int mvx_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm, int *rcs);
+
 /* ---- query -------------------------------------------------------------------- */
 int mvx_get_obj_dir(const mvx_prob *P);               /* util.cpp:51 */
 int mvx_get_num_rows(const mvx_prob *P);              /* gmi.cpp:15 */
@@ -146,6 +152,9 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf);
 /* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
    for measurement sweeps -- results are identical for every setting */
 void mvx_set_tuning(int tr, int hot, int nt);
+/* replay each batch of queued pivots as one captured hipGraph instead of eager launches (default
+   off: measured no gain on MI355X -- small-kernel dispatch is command-processor-bound) */
+void mvx_use_graphs(int on);
 /* block until all work queued on the engine stream has finished */
 void mvx_sync(void);
 

@@ -49,6 +49,9 @@ typedef struct mvx_lp_api {
   int (*get_mat_row)(const void *P, int i, int *ind, double *val);
   int (*eval_tab_row)(const void *P, int k, int *ind, double *val);
   int (*get_it_cnt)(const void *P);
+  /* optional (may be NULL): solve `count` independent handles concurrently, same results as
+     `count` simplex calls -- used for the two children of a branch (bs.cpp:279,287) */
+  int (*simplex_batch)(void **probs, int count, const void *parm, int *rcs);
 } mvx_lp_api;
 
 const mvx_lp_api *mvx_hip_lp_api(void);

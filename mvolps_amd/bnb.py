@@ -14,12 +14,13 @@ _FIELDS = [
     "get_col_stat", "get_row_stat", "get_row_ub", "get_col_ub", "get_col_lb", "get_col_type", "get_mat_row", "eval_tab_row",
     "get_it_cnt",
 ]
+_OPTIONAL = ["simplex_batch"]
 
 
 class LpApiTable(C.Structure):
     """struct mvx_lp_api: the GLPK-shaped function table the driver calls through."""
 
-    _fields_ = [(name, C.c_void_p) for name in _FIELDS]
+    _fields_ = [(name, C.c_void_p) for name in _FIELDS + _OPTIONAL]
 
 
 class BnbParams(C.Structure):
@@ -73,6 +74,9 @@ def table_from(api):
     for name in _FIELDS:
         fn = getattr(api.lib, api.prefix + name)
         setattr(t, name, C.cast(fn, C.c_void_p).value)
+    for name in _OPTIONAL:  # optional entries stay NULL when the library does not export them
+        fn = getattr(api.lib, api.prefix + name, None) if hasattr(api.lib, api.prefix + name) else None
+        setattr(t, name, C.cast(fn, C.c_void_p).value if fn is not None else None)
     return t
 
 

@@ -368,8 +368,6 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
         else
           api->set_col_bnds(S2->prob, pick, MVX_UP, 0, std::floor(bound));
       }
-      solve(api, S2->prob, rec); // bs.cpp:279
-      S2->upperBound = api->get_obj_val(S2->prob);
       if (quirks) {
         api->set_col_bnds(S3->prob, pick, MVX_LO, std::ceil(bound), 0); // bs.cpp:282
       } else {
@@ -380,7 +378,18 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
         else
           api->set_col_bnds(S3->prob, pick, MVX_LO, std::ceil(bound), 0);
       }
-      solve(api, S3->prob, rec); // bs.cpp:287
+      // bs.cpp:279 and :287 solve two independent clones; an engine with a batch entry runs them
+      // side by side (identical results), otherwise one after the other as the reference does
+      if (api->simplex_batch) {
+        void *pair[2] = {S2->prob, S3->prob};
+        const int before = api->get_it_cnt(S2->prob) + api->get_it_cnt(S3->prob);
+        api->simplex_batch(pair, 2, nullptr, nullptr);
+        rec.pivots += api->get_it_cnt(S2->prob) + api->get_it_cnt(S3->prob) - before;
+      } else {
+        solve(api, S2->prob, rec);
+        solve(api, S3->prob, rec);
+      }
+      S2->upperBound = api->get_obj_val(S2->prob);
       S3->upperBound = api->get_obj_val(S3->prob);
       rec.bound[(size_t)S2->oid] = S2->upperBound;
       rec.bound[(size_t)S3->oid] = S3->upperBound;
@@ -445,6 +454,9 @@ const mvx_lp_api g_hip_api = {
     [](const void *P, int i, int *ind, double *val) { return mvx_get_mat_row((const mvx_prob *)P, i, ind, val); },
     [](const void *P, int k, int *ind, double *val) { return mvx_eval_tab_row((const mvx_prob *)P, k, ind, val); },
     [](const void *P) { return mvx_get_it_cnt((const mvx_prob *)P); },
+    [](void **probs, int count, const void *parm, int *rcs) {
+      return mvx_simplex_batch((mvx_prob **)probs, count, (const mvx_smcp *)parm, rcs);
+    },
 };
 
 } // namespace

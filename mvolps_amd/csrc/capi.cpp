@@ -242,6 +242,9 @@ void mvx_init_smcp(mvx_smcp *parm) {
 }
 
 int mvx_simplex(mvx_prob *P, const mvx_smcp *parm) { return mvx::engine_simplex(P, parm); }
+int mvx_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm, int *rcs) {
+  return mvx::engine_simplex_batch(probs, count, parm, rcs);
+}
 
 int mvx_get_obj_dir(const mvx_prob *P) { return P->dir; }
 int mvx_get_num_rows(const mvx_prob *P) { return P->m; }
@@ -412,6 +415,7 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
   return mvx::engine_unpack(dst, dev_buf);
 }
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
+void mvx_use_graphs(int on) { mvx::use_graphs(on); }
 void mvx_profile_enable(int on) { mvx::profile_enable(on); }
 void mvx_profile_reset(void) { mvx::profile_reset(); }
 double mvx_profile_update_ms(void) { return mvx::profile_update_ms(); }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <vector>
 
 #include "engine.hpp"
@@ -31,8 +32,8 @@ int fused_nrb_max(int m);
 void launch_fboot(Ctl *, int n, hipStream_t);
 void launch_fa(Ctl *, int n, hipStream_t);
 void launch_fb(Ctl *, int m, int n, hipStream_t);
-void launch_select(Ctl *, hipStream_t);
-void launch_update(Ctl *, int m, int n, hipStream_t);
+void launch_select(Ctl *, hipStream_t, int slots = 1);
+void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1);
 void launch_p1_head(Ctl *, hipStream_t);
 void launch_p1_select(Ctl *, hipStream_t);
 void launch_rowcomb(Ctl *, int m, int n, int respect_done, hipStream_t);
@@ -41,13 +42,15 @@ void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double 
 void launch_set_nonbasic(double *nlb, double *nub, int *nflag, int j, double lb, double ub, int flag, hipStream_t);
 void launch_add_rows(double *T, int ld, int n, int *bvar, double *blb, double *bub, int *nvar, int first, int nrs, int m_new,
                      hipStream_t);
-void launch_export(Ctl *, unsigned char *stage, int m, int n, int force, hipStream_t);
+void launch_export(Ctl *, unsigned char *stage, int m, int n, int force, hipStream_t, int slots = 1, size_t slot_stride = 0);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------ context
-struct Context {
-  int dev = -1;
+// One solve context = one HIP stream with its own control block, scratch and staging.  The main
+// context serves every single-handle call; mvx_simplex_batch runs independent node solves on a
+// pool of them concurrently (B&B children, bs.cpp:279,287, are independent LPs).
+struct SolveCtx {
   hipStream_t stream = nullptr;
   Ctl *d_ctl = nullptr;
   Ctl *h_ctl = nullptr; // pinned
@@ -60,18 +63,34 @@ struct Context {
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
   size_t stage_bytes = 0;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  // captured launch sequences: kernels take only Ctl*, so one hipGraph per (grid geometry, depth)
+  // serves every handle that runs on this context
+  struct GraphKey {
+    int kind, m_grid, n, depth, m_cap, ld;
+    bool operator<(const GraphKey &o) const {
+      return std::tie(kind, m_grid, n, depth, m_cap, ld) < std::tie(o.kind, o.m_grid, o.n, o.depth, o.m_cap, o.ld);
+    }
+  };
+  std::map<GraphKey, hipGraphExec_t> graphs;
+};
+
+struct Context {
+  int dev = -1;
+  SolveCtx main;
+  std::vector<SolveCtx *> pool;
   // slab recycling (B&B clones come and go at one size)
   std::multimap<size_t, void *> free_slabs;
   size_t cached_bytes = 0;
-  // profiling
+  // profiling (main context only)
   bool prof = false;
   double prof_update_ms = 0.0;
   long long prof_update_n = 0;
   std::vector<hipEvent_t> ev_pool;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
 };
 
 static Context *g_ctx = nullptr;
+static bool g_use_graphs = false; // measured: no gain (dispatch is command-processor-bound, not host-bound)
 static int g_requested_dev = -1;
 
 int device_count() {
@@ -86,6 +105,14 @@ int set_device(int dev) {
   return 0;
 }
 
+static void init_solve_ctx(SolveCtx &sc) {
+  HIPCHECK(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+  HIPCHECK(hipMalloc((void **)&sc.d_ctl, sizeof(Ctl)));
+  HIPCHECK(hipHostMalloc((void **)&sc.h_ctl, sizeof(Ctl)));
+  HIPCHECK(hipEventCreate(&sc.ev_a));
+  HIPCHECK(hipEventCreate(&sc.ev_b));
+}
+
 static Context &ctx() {
   if (g_ctx) return *g_ctx;
   int n = device_count();
@@ -98,31 +125,32 @@ static Context &ctx() {
   Context *c = new Context();
   c->dev = g_requested_dev >= 0 ? g_requested_dev : 0;
   HIPCHECK(hipSetDevice(c->dev));
-  HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHECK(hipMalloc((void **)&c->d_ctl, sizeof(Ctl)));
-  HIPCHECK(hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl)));
-  HIPCHECK(hipEventCreate(&c->ev_a));
-  HIPCHECK(hipEventCreate(&c->ev_b));
+  init_solve_ctx(c->main);
   g_ctx = c;
   return *c;
 }
 
 void sync_stream() {
-  if (g_ctx) HIPCHECK(hipStreamSynchronize(g_ctx->stream));
+  if (!g_ctx) return;
+  HIPCHECK(hipStreamSynchronize(g_ctx->main.stream));
+  for (SolveCtx *sc : g_ctx->pool) HIPCHECK(hipStreamSynchronize(sc->stream));
 }
 
 static size_t stage_size(int m_cap, int ld) {
   return align_up(sizeof(Ctl) + (size_t)(m_cap + 1) * 8 + (size_t)ld * 8 + (size_t)(m_cap + 1) * 4 + (size_t)ld * 8, 256);
 }
 
-static void ensure_scratch(Context &c, int m_cap, int ld) {
-  if (m_cap <= c.sc_m_cap && ld <= c.sc_ld) return;
-  HIPCHECK(hipStreamSynchronize(c.stream));
-  int mc = m_cap > c.sc_m_cap ? m_cap : c.sc_m_cap;
-  int l = ld > c.sc_ld ? ld : c.sc_ld;
-  if (c.scratch) HIPCHECK(hipFree(c.scratch));
-  if (c.d_stage) HIPCHECK(hipFree(c.d_stage));
-  if (c.h_stage) HIPCHECK(hipHostFree(c.h_stage));
+static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
+  if (m_cap <= sc.sc_m_cap && ld <= sc.sc_ld) return;
+  HIPCHECK(hipStreamSynchronize(sc.stream));
+  int mc = m_cap > sc.sc_m_cap ? m_cap : sc.sc_m_cap;
+  int l = ld > sc.sc_ld ? ld : sc.sc_ld;
+  // captured graphs hold the staging pointers: drop them with the buffers
+  for (auto &kv : sc.graphs) HIPCHECK(hipGraphExecDestroy(kv.second));
+  sc.graphs.clear();
+  if (sc.scratch) HIPCHECK(hipFree(sc.scratch));
+  if (sc.d_stage) HIPCHECK(hipFree(sc.d_stage));
+  if (sc.h_stage) HIPCHECK(hipHostFree(sc.h_stage));
   const int nchunks = (mc + ROWCOMB_CHUNK - 1) / ROWCOMB_CHUNK + 1;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
@@ -137,28 +165,28 @@ static void ensure_scratch(Context &c, int m_cap, int ld) {
   size_t o_bc0 = carve((size_t)(mc + 1) * 8), o_bc1 = carve((size_t)(mc + 1) * 8);
   size_t o_pp0 = carve((size_t)fused_npb(l) * sizeof(Cand)), o_pp1 = carve((size_t)fused_npb(l) * sizeof(Cand));
   size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
-  HIPCHECK(hipMalloc(&c.scratch, off));
-  HIPCHECK(hipMemsetAsync(c.scratch, 0, off, c.stream));
-  unsigned char *b = (unsigned char *)c.scratch;
-  c.d_colq = (double *)(b + o_colq);
-  c.d_srow = (double *)(b + o_srow);
-  c.d_cost1 = (double *)(b + o_cost1);
-  c.d_wts = (double *)(b + o_wts);
-  c.d_rcbase = (double *)(b + o_rcb);
-  c.d_gflag = (int *)(b + o_g);
-  c.d_part = (double *)(b + o_part);
-  c.d_colqx[0] = (double *)(b + o_cx0);
-  c.d_colqx[1] = (double *)(b + o_cx1);
-  c.d_betac[0] = (double *)(b + o_bc0);
-  c.d_betac[1] = (double *)(b + o_bc1);
-  c.d_pp[0] = (Cand *)(b + o_pp0);
-  c.d_pp[1] = (Cand *)(b + o_pp1);
-  c.d_rp = (Cand *)(b + o_rp);
-  c.stage_bytes = stage_size(mc, l);
-  HIPCHECK(hipMalloc((void **)&c.d_stage, c.stage_bytes));
-  HIPCHECK(hipHostMalloc((void **)&c.h_stage, c.stage_bytes));
-  c.sc_m_cap = mc;
-  c.sc_ld = l;
+  HIPCHECK(hipMalloc(&sc.scratch, off));
+  HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
+  unsigned char *b = (unsigned char *)sc.scratch;
+  sc.d_colq = (double *)(b + o_colq);
+  sc.d_srow = (double *)(b + o_srow);
+  sc.d_cost1 = (double *)(b + o_cost1);
+  sc.d_wts = (double *)(b + o_wts);
+  sc.d_rcbase = (double *)(b + o_rcb);
+  sc.d_gflag = (int *)(b + o_g);
+  sc.d_part = (double *)(b + o_part);
+  sc.d_colqx[0] = (double *)(b + o_cx0);
+  sc.d_colqx[1] = (double *)(b + o_cx1);
+  sc.d_betac[0] = (double *)(b + o_bc0);
+  sc.d_betac[1] = (double *)(b + o_bc1);
+  sc.d_pp[0] = (Cand *)(b + o_pp0);
+  sc.d_pp[1] = (Cand *)(b + o_pp1);
+  sc.d_rp = (Cand *)(b + o_rp);
+  sc.stage_bytes = stage_size(mc, l);
+  HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
+  HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
+  sc.sc_m_cap = mc;
+  sc.sc_ld = l;
 }
 
 // ------------------------------------------------------------------------------- slabs
@@ -214,7 +242,7 @@ static void *slab_alloc(Context &c, size_t bytes) {
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
     // drop the cache and retry once
-    HIPCHECK(hipStreamSynchronize(c.stream));
+    sync_stream();
     for (auto &kv : c.free_slabs) (void)hipFree(kv.second);
     c.free_slabs.clear();
     c.cached_bytes = 0;
@@ -226,13 +254,15 @@ static void *slab_alloc(Context &c, size_t bytes) {
 void release_device(mvx_prob *P) {
   if (!P->slab) return;
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   // the stream is in-order: work already queued on the slab finishes before any reuse
   const size_t cache_limit = (size_t)8 << 30;
   if (c.cached_bytes + P->slab_bytes <= cache_limit) {
     c.free_slabs.emplace(P->slab_bytes, P->slab);
     c.cached_bytes += P->slab_bytes;
   } else {
-    HIPCHECK(hipStreamSynchronize(c.stream));
+    HIPCHECK(hipStreamSynchronize(sc.stream));
     HIPCHECK(hipFree(P->slab));
   }
   P->slab = nullptr;
@@ -243,6 +273,8 @@ void release_device(mvx_prob *P) {
 
 static void alloc_device(mvx_prob *P, int m_cap, int ld) {
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   SlabLayout L = slab_layout(m_cap, ld);
   void *slab = slab_alloc(c, L.total);
   bind_slab(P, slab, m_cap, ld);
@@ -254,6 +286,8 @@ static int ld_for(int n) { return (int)align_up((size_t)n + 1, LD_ALIGN); }
 static void grow_rows(mvx_prob *P, int m_new) {
   if (m_new + ROW_SPARE <= P->m_cap) return;
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   const int cap = m_new + ROW_SLACK;
   void *o_slab = P->slab;
   const size_t o_bytes = P->slab_bytes;
@@ -263,14 +297,14 @@ static void grow_rows(mvx_prob *P, int m_new) {
   SlabLayout Ln = slab_layout(cap, ld);
   void *slab = slab_alloc(c, Ln.total);
   bind_slab(P, slab, cap, ld);
-  HIPCHECK(hipMemcpyAsync(P->d_T, oT, (size_t)o_rows * ld * 8, hipMemcpyDeviceToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_bvar, obvar, (size_t)o_rows * 4, hipMemcpyDeviceToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_blb, oblb, (size_t)o_rows * 8, hipMemcpyDeviceToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_bub, obub, (size_t)o_rows * 8, hipMemcpyDeviceToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_nvar, onvar, (size_t)ld * 4, hipMemcpyDeviceToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_nflag, onflag, (size_t)ld * 4, hipMemcpyDeviceToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_nlb, onlb, (size_t)ld * 8, hipMemcpyDeviceToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_nub, onub, (size_t)ld * 8, hipMemcpyDeviceToDevice, c.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_T, oT, (size_t)o_rows * ld * 8, hipMemcpyDeviceToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_bvar, obvar, (size_t)o_rows * 4, hipMemcpyDeviceToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_blb, oblb, (size_t)o_rows * 8, hipMemcpyDeviceToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_bub, obub, (size_t)o_rows * 8, hipMemcpyDeviceToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nvar, onvar, (size_t)ld * 4, hipMemcpyDeviceToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nflag, onflag, (size_t)ld * 4, hipMemcpyDeviceToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nlb, onlb, (size_t)ld * 8, hipMemcpyDeviceToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nub, onub, (size_t)ld * 8, hipMemcpyDeviceToDevice, sc.stream));
   // recycle the old slab (in-order stream: the copies above complete before any reuse)
   c.free_slabs.emplace(o_bytes, o_slab);
   c.cached_bytes += o_bytes;
@@ -312,34 +346,34 @@ static inline void var_bounds(const mvx_prob *P, int k, double *lb, double *ub) 
   }
 }
 
-static void fill_ctl(Context &c, mvx_prob *P, Ctl *h) {
+static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   std::memset(h, 0, sizeof(Ctl));
   h->T = P->d_T;
   h->bvar = P->d_bvar; h->blb = P->d_blb; h->bub = P->d_bub;
   h->nvar = P->d_nvar; h->nflag = P->d_nflag; h->nlb = P->d_nlb; h->nub = P->d_nub;
-  h->colq = c.d_colq; h->srow = c.d_srow; h->cost1 = c.d_cost1; h->wts = c.d_wts;
-  h->gflag = c.d_gflag; h->part = c.d_part; h->rc_base = nullptr; h->rc_out = c.d_cost1;
+  h->colq = sc.d_colq; h->srow = sc.d_srow; h->cost1 = sc.d_cost1; h->wts = sc.d_wts;
+  h->gflag = sc.d_gflag; h->part = sc.d_part; h->rc_base = nullptr; h->rc_out = sc.d_cost1;
   h->m = P->m; h->n = P->n; h->ld = P->ld; h->m_cap = P->m_cap;
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = 1e-9; h->tol_dj = 1e-9; h->tol_piv = 1e-9;
   h->phase = PH_START; h->done = D_RUN; h->budget = -1;
-  h->colqx[0] = c.d_colqx[0]; h->colqx[1] = c.d_colqx[1];
-  h->betac[0] = c.d_betac[0]; h->betac[1] = c.d_betac[1];
-  h->pp[0] = c.d_pp[0]; h->pp[1] = c.d_pp[1]; h->rp = c.d_rp;
+  h->colqx[0] = sc.d_colqx[0]; h->colqx[1] = sc.d_colqx[1];
+  h->betac[0] = sc.d_betac[0]; h->betac[1] = sc.d_betac[1];
+  h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
   h->npb = fused_npb(P->n); h->nrb = 0; // nrb is published by k_fb (its grid height)
   h->fstate = F_OFF;
 }
 
-static void upload_ctl(Context &c) {
-  HIPCHECK(hipMemcpyAsync(c.d_ctl, c.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, c.stream));
+static void upload_ctl(SolveCtx &sc) {
+  HIPCHECK(hipMemcpyAsync(sc.d_ctl, sc.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, sc.stream));
 }
 
 // copy the staging buffer back and refresh the host mirrors
-static void pull_stage(Context &c, mvx_prob *P, bool mirrors) {
-  HIPCHECK(hipMemcpyAsync(c.h_stage, c.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, c.stream));
-  HIPCHECK(hipStreamSynchronize(c.stream));
+static void pull_stage(SolveCtx &sc, mvx_prob *P, bool mirrors) {
+  HIPCHECK(hipMemcpyAsync(sc.h_stage, sc.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, sc.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
   if (!mirrors) return;
-  const unsigned char *s = c.h_stage;
+  const unsigned char *s = sc.h_stage;
   const double *beta = (const double *)(s + sizeof(Ctl));
   const double *dj = beta + (P->m_cap + 1);
   const int *bv = (const int *)(dj + P->ld);
@@ -358,21 +392,25 @@ void refresh_solution(const mvx_prob *Pc) {
   mvx_prob *P = const_cast<mvx_prob *>(Pc);
   if (!P->valid || P->sol_fresh) return;
   Context &c = ctx();
-  ensure_scratch(c, P->m_cap, P->ld);
-  fill_ctl(c, P, c.h_ctl);
-  upload_ctl(c);
-  launch_export(c.d_ctl, c.d_stage, P->m, P->n, 1, c.stream);
-  pull_stage(c, P, true);
+  SolveCtx &sc = c.main;
+  (void)sc;
+  ensure_scratch(sc, P->m_cap, P->ld);
+  fill_ctl(sc, P, sc.h_ctl);
+  upload_ctl(sc);
+  launch_export(sc.d_ctl, sc.d_stage, P->m, P->n, 1, sc.stream);
+  pull_stage(sc, P, true);
 }
 
 // ---------------------------------------------------------------------- tableau build
 static void build_slack_tableau(mvx_prob *P) {
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   const int m = P->m, n = P->n;
   const int ld = ld_for(n);
   if (P->slab && (P->ld != ld || P->m_cap < m + ROW_SPARE)) release_device(P);
   if (!P->slab) alloc_device(P, m + ROW_SLACK, ld);
-  ensure_scratch(c, P->m_cap, P->ld);
+  ensure_scratch(sc, P->m_cap, P->ld);
   P->bvar.assign((size_t)m + 1, 0);
   P->nvar.assign((size_t)n + 1, 0);
   P->nflag.assign((size_t)n + 1, 0);
@@ -418,23 +456,23 @@ static void build_slack_tableau(mvx_prob *P) {
         row[0] = acc;
       }
     }
-    HIPCHECK(hipMemcpyAsync(P->d_T + r0 * ld, bounce, (r1 - r0) * ld * 8, hipMemcpyHostToDevice, c.stream));
-    HIPCHECK(hipStreamSynchronize(c.stream));
+    HIPCHECK(hipMemcpyAsync(P->d_T + r0 * ld, bounce, (r1 - r0) * ld * 8, hipMemcpyHostToDevice, sc.stream));
+    HIPCHECK(hipStreamSynchronize(sc.stream));
   }
   HIPCHECK(hipHostFree(bounce));
-  HIPCHECK(hipMemcpyAsync(P->d_bvar, P->bvar.data(), (size_t)(m + 1) * 4, hipMemcpyHostToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_blb, blb.data(), (size_t)(m + 1) * 8, hipMemcpyHostToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_bub, bub.data(), (size_t)(m + 1) * 8, hipMemcpyHostToDevice, c.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_bvar, P->bvar.data(), (size_t)(m + 1) * 4, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_blb, blb.data(), (size_t)(m + 1) * 8, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_bub, bub.data(), (size_t)(m + 1) * 8, hipMemcpyHostToDevice, sc.stream));
   std::vector<int> nv((size_t)ld, 0), nf((size_t)ld, MVX_NS);
   for (int j = 1; j <= n; j++) {
     nv[j] = P->nvar[j];
     nf[j] = P->nflag[j];
   }
-  HIPCHECK(hipMemcpyAsync(P->d_nvar, nv.data(), (size_t)ld * 4, hipMemcpyHostToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_nflag, nf.data(), (size_t)ld * 4, hipMemcpyHostToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_nlb, nlb.data(), (size_t)ld * 8, hipMemcpyHostToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(P->d_nub, nub.data(), (size_t)ld * 8, hipMemcpyHostToDevice, c.stream));
-  HIPCHECK(hipStreamSynchronize(c.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nvar, nv.data(), (size_t)ld * 4, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nflag, nf.data(), (size_t)ld * 4, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nlb, nlb.data(), (size_t)ld * 8, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(P->d_nub, nub.data(), (size_t)ld * 8, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
   rebuild_pos(P);
   P->valid = true;
   P->sol_fresh = false;
@@ -451,157 +489,448 @@ static void flush_update_events(Context &c, size_t used) {
   }
 }
 
-int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
-  mvx_smcp dflt;
-  if (!parm) {
-    mvx_init_smcp(&dflt);
-    parm = &dflt;
-  }
-  if (P->m < 1 || P->n < 1) {
-    P->status = MVX_UNDEF;
-    return MVX_EFAIL;
-  }
-  Context &c = ctx();
-  if (!P->valid) build_slack_tableau(P);
-  ensure_scratch(c, P->m_cap, P->ld);
-  Ctl *h = c.h_ctl;
-  fill_ctl(c, P, h);
-  h->tol_bnd = parm->tol_bnd;
-  h->tol_dj = parm->tol_dj;
-  h->tol_piv = parm->tol_piv;
-  h->budget = parm->it_lim;
-  upload_ctl(c);
-  HIPCHECK(hipEventRecord(c.ev_a, c.stream));
-
-  const int m = P->m, n = P->n;
-  int batch = 8;
+// A solve is a small host-side state machine around queued launches, so that several of them
+// can be in flight on different streams (engine_simplex_batch): begin -> {enqueue, sync, collect}*.
+struct SolveJob {
+  mvx_prob *P = nullptr;
+  SolveCtx *sc = nullptr;
+  mvx_smcp parm;
+  enum { MAIN, PHASE1, FINAL } mode = MAIN;
+  int batch = 8, pb = 4;
   int done = D_RUN;
-  int seen_steps = 0; // pivots + flips already accounted to the profile
-  int seen_pivots = 0;
-  bool try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
+  bool try_fused = false;
+  int seen_steps = 0, seen_pivots = 0;
+  size_t ev_used = 0;
+  bool profiled = false;
+  int rc = 0;
   Ctl snap;
-  for (;;) {
-    size_t ev_used = 0;
-    if (c.prof && c.ev_pool.size() < (size_t)2 * batch + 2) { // sized for the largest batch
-      size_t old = c.ev_pool.size();
-      c.ev_pool.resize((size_t)2 * batch + 2);
-      for (size_t k = old; k < c.ev_pool.size(); k++) HIPCHECK(hipEventCreate(&c.ev_pool[k]));
+};
+
+static void stage_copy_async(SolveCtx &sc, const mvx_prob *P) {
+  HIPCHECK(hipMemcpyAsync(sc.h_stage, sc.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, sc.stream));
+}
+
+static void job_begin(Context &c, SolveJob &J) {
+  mvx_prob *P = J.P;
+  SolveCtx &sc = *J.sc;
+  ensure_scratch(sc, P->m_cap, P->ld);
+  Ctl *h = sc.h_ctl;
+  fill_ctl(sc, P, h);
+  h->tol_bnd = J.parm.tol_bnd;
+  h->tol_dj = J.parm.tol_dj;
+  h->tol_piv = J.parm.tol_piv;
+  h->budget = J.parm.it_lim;
+  upload_ctl(sc);
+  HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
+  J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
+  J.profiled = c.prof && J.sc == &c.main;
+}
+
+static void job_enqueue(Context &c, SolveJob &J) {
+  mvx_prob *P = J.P;
+  SolveCtx &sc = *J.sc;
+  const int m = P->m, n = P->n;
+  J.ev_used = 0;
+  if (J.mode == SolveJob::FINAL) {
+    HIPCHECK(hipEventRecord(sc.ev_b, sc.stream));
+    launch_export(sc.d_ctl, sc.d_stage, m, n, 1, sc.stream); // forced: phase-1 exits and FAIL paths included
+    stage_copy_async(sc, P);
+    return;
+  }
+  if (J.mode == SolveJob::PHASE1) {
+    // host-driven phase 1: per iteration head -> cost row (rowcomb) -> select -> update
+    for (int k = 0; k < J.pb; k++) {
+      launch_p1_head(sc.d_ctl, sc.stream);
+      launch_rowcomb(sc.d_ctl, m, n, 1, sc.stream);
+      launch_p1_select(sc.d_ctl, sc.stream);
+      launch_update(sc.d_ctl, m, n, sc.stream);
     }
-    // with a pivot limit, never queue more pivots than the limit still allows (+1 launch so that
-    // k_select can observe the exhausted budget): keeps no-op launches out of profiles
-    const int remaining = (parm->it_lim >= 0) ? std::max(0, parm->it_lim - seen_pivots) : (1 << 30);
-    auto ev = [&]() {
-      if (c.prof) HIPCHECK(hipEventRecord(c.ev_pool[ev_used++], c.stream));
-    };
-    if (try_fused) {
+    launch_export(sc.d_ctl, sc.d_stage, m, n, 0, sc.stream);
+    stage_copy_async(sc, P);
+    return;
+  }
+  const int batch = J.batch;
+  if (J.profiled && c.ev_pool.size() < (size_t)2 * batch + 2) { // sized for the largest batch
+    size_t old = c.ev_pool.size();
+    c.ev_pool.resize((size_t)2 * batch + 2);
+    for (size_t k = old; k < c.ev_pool.size(); k++) HIPCHECK(hipEventCreate(&c.ev_pool[k]));
+  }
+  // with a pivot limit, never queue more pivots than the limit still allows (+1 launch so that
+  // k_select can observe the exhausted budget): keeps no-op launches out of profiles
+  const int remaining = (J.parm.it_lim >= 0) ? std::max(0, J.parm.it_lim - J.seen_pivots) : (1 << 30);
+  auto ev = [&]() {
+    if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[J.ev_used++], sc.stream));
+  };
+  // The whole batch (launches + export + staging copy) is one hipGraph replay unless per-kernel
+  // events are wanted: eager launches cost the host ~3.5 us each, which bounds small tableaux and
+  // concurrent node solves; a replay is one call.
+  const bool use_graph = g_use_graphs && !J.profiled;
+  int depth;
+  SolveCtx::GraphKey key;
+  if (J.try_fused) {
+    depth = std::max(0, std::min(batch - 1, remaining - 1));
+    key = {1, m, n, depth, P->m_cap, P->ld};
+  } else {
+    depth = std::max(1, std::min(batch, remaining));
+    key = {0, P->m_cap, n, depth, P->m_cap, P->ld};
+  }
+  auto body = [&](int m_grid) {
+    if (J.try_fused) {
       // one generic step settles the phase; if it is primal phase 2 the fused two-kernel pipeline
       // (k_fa / k_fb) takes over, otherwise its launches return at once
-      launch_select(c.d_ctl, c.stream);
+      launch_select(sc.d_ctl, sc.stream);
       ev();
-      launch_update(c.d_ctl, m, n, c.stream);
+      launch_update(sc.d_ctl, m_grid, n, sc.stream);
       ev();
-      const int nf = std::min(batch - 1, remaining - 1);
-      if (nf > 0) {
-        launch_fboot(c.d_ctl, n, c.stream);
-        launch_fb(c.d_ctl, m, n, c.stream);
-        for (int k = 0; k < nf; k++) {
-          launch_fa(c.d_ctl, n, c.stream);
+      if (depth > 0) {
+        launch_fboot(sc.d_ctl, n, sc.stream);
+        launch_fb(sc.d_ctl, m_grid, n, sc.stream);
+        for (int k = 0; k < depth; k++) {
+          launch_fa(sc.d_ctl, n, sc.stream);
           ev();
-          launch_fb(c.d_ctl, m, n, c.stream);
+          launch_fb(sc.d_ctl, m_grid, n, sc.stream);
           ev();
         }
       }
     } else {
-      const int nb = std::max(1, std::min(batch, remaining));
-      for (int k = 0; k < nb; k++) {
-        launch_select(c.d_ctl, c.stream);
+      for (int k = 0; k < depth; k++) {
+        launch_select(sc.d_ctl, sc.stream);
         ev();
-        launch_update(c.d_ctl, m, n, c.stream);
+        launch_update(sc.d_ctl, m_grid, n, sc.stream);
         ev();
       }
     }
-    launch_export(c.d_ctl, c.d_stage, m, n, 0, c.stream);
-    pull_stage(c, P, false);
-    std::memcpy(&snap, c.h_stage, sizeof(Ctl));
-    if (c.prof) {
-      // once the solve finishes inside a batch the queued-ahead launches are no-ops; only the
-      // leading launches that really stepped are timed
-      const int steps_now = snap.it_cnt + snap.n_flips;
-      flush_update_events(c, std::min(ev_used, (size_t)2 * (size_t)(steps_now - seen_steps)));
-      seen_steps = steps_now;
-    }
-    done = snap.done;
-    seen_pivots = snap.it_cnt;
-    try_fused = (snap.phase == PH_PRIMAL2);
-    if (done == D_NEED_PHASE1) {
-      // host-driven phase 1: per iteration head -> cost row (rowcomb) -> select -> update
-      snap.done = D_RUN;
-      snap.phase = PH_PHASE1;
-      snap.rc_base = nullptr;
-      snap.rc_out = c.d_cost1;
-      *h = snap;
-      upload_ctl(c);
-      int pb = 4;
-      for (;;) {
-        for (int k = 0; k < pb; k++) {
-          launch_p1_head(c.d_ctl, c.stream);
-          launch_rowcomb(c.d_ctl, m, n, 1, c.stream);
-          launch_p1_select(c.d_ctl, c.stream);
-          launch_update(c.d_ctl, m, n, c.stream);
-        }
-        launch_export(c.d_ctl, c.d_stage, m, n, 0, c.stream);
-        pull_stage(c, P, false);
-        std::memcpy(&snap, c.h_stage, sizeof(Ctl));
-        if (snap.done != D_RUN) break;
-        pb = std::min(pb * 2, 64);
-      }
-      if (snap.done == D_PFEAS) {
-        snap.rounds++;
-        if (snap.rounds >= 64) {
-          done = D_FAIL;
-          break;
-        }
-        snap.done = D_RUN;
-        snap.phase = PH_START;
-        *h = snap;
-        upload_ctl(c);
-        batch = 8;
-        continue;
-      }
-      done = snap.done;
-      break;
-    }
-    if (done != D_RUN) break;
-    batch = std::min(batch * 2, 256);
+    launch_export(sc.d_ctl, sc.d_stage, m_grid, n, 0, sc.stream);
+    stage_copy_async(sc, P);
+  };
+  if (!use_graph) {
+    body(m);
+    return;
   }
-  HIPCHECK(hipEventRecord(c.ev_b, c.stream));
-  // final export with mirrors (forced: phase-1 exits and FAIL paths included)
-  launch_export(c.d_ctl, c.d_stage, m, n, 1, c.stream);
-  pull_stage(c, P, true);
-  std::memcpy(&snap, c.h_stage, sizeof(Ctl));
-  float ms = 0.f;
-  HIPCHECK(hipEventElapsedTime(&ms, c.ev_a, c.ev_b));
-  P->last_ms = ms;
+  auto it = sc.graphs.find(key);
+  if (it == sc.graphs.end()) {
+    if (sc.graphs.size() >= 64) { // bounded cache: drop everything, shapes have moved on
+      for (auto &kv : sc.graphs) HIPCHECK(hipGraphExecDestroy(kv.second));
+      sc.graphs.clear();
+    }
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHECK(hipStreamBeginCapture(sc.stream, hipStreamCaptureModeRelaxed));
+    body(key.m_grid);
+    HIPCHECK(hipStreamEndCapture(sc.stream, &g));
+    HIPCHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIPCHECK(hipGraphDestroy(g));
+    it = sc.graphs.emplace(key, ge).first;
+  }
+  HIPCHECK(hipGraphLaunch(it->second, sc.stream));
+}
+
+// the job's stream has been synchronised; returns true when the solve is complete
+static bool job_collect(Context &c, SolveJob &J) {
+  mvx_prob *P = J.P;
+  SolveCtx &sc = *J.sc;
+  Ctl &snap = J.snap;
+  std::memcpy(&snap, sc.h_stage, sizeof(Ctl));
+  if (J.mode == SolveJob::FINAL) {
+    const unsigned char *s = sc.h_stage;
+    const double *beta = (const double *)(s + sizeof(Ctl));
+    const double *dj = beta + (P->m_cap + 1);
+    const int *bv = (const int *)(dj + P->ld);
+    const int *nv = bv + (P->m_cap + 1);
+    const int *nf = nv + P->ld;
+    P->beta.assign(beta, beta + P->m + 1);
+    P->dj.assign(dj, dj + P->n + 1);
+    P->bvar.assign(bv, bv + P->m + 1);
+    P->nvar.assign(nv, nv + P->n + 1);
+    P->nflag.assign(nf, nf + P->n + 1);
+    rebuild_pos(P);
+    P->sol_fresh = true;
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, sc.ev_a, sc.ev_b));
+    P->last_ms = ms;
+    P->it_cnt += snap.it_cnt;
+    P->hint_dual = false;
+    switch (J.done) {
+      case D_OPT: P->status = MVX_OPT; J.rc = 0; break;
+      case D_UNBND: P->status = MVX_UNBND; J.rc = 0; break;
+      case D_NOFEAS: P->status = MVX_NOFEAS; J.rc = 0; break;
+      case D_ITLIM:
+        P->status = (snap.phase == PH_PRIMAL2) ? MVX_FEAS : MVX_INFEAS;
+        J.rc = MVX_EITLIM;
+        break;
+      default: P->status = MVX_UNDEF; J.rc = MVX_EFAIL; break;
+    }
+    return true;
+  }
+  if (J.mode == SolveJob::PHASE1) {
+    if (snap.done == D_RUN) {
+      J.pb = std::min(J.pb * 2, 64);
+      return false;
+    }
+    if (snap.done == D_PFEAS) {
+      snap.rounds++;
+      if (snap.rounds >= 64) {
+        J.done = D_FAIL;
+        J.mode = SolveJob::FINAL;
+        return false;
+      }
+      snap.done = D_RUN;
+      snap.phase = PH_START;
+      *sc.h_ctl = snap;
+      upload_ctl(sc);
+      J.mode = SolveJob::MAIN;
+      J.batch = 8;
+      J.try_fused = false;
+      return false;
+    }
+    J.done = snap.done;
+    J.mode = SolveJob::FINAL;
+    return false;
+  }
+  if (J.profiled) {
+    // once the solve finishes inside a batch the queued-ahead launches are no-ops; only the
+    // leading launches that really stepped are timed
+    const int steps_now = snap.it_cnt + snap.n_flips;
+    flush_update_events(c, std::min(J.ev_used, (size_t)2 * (size_t)(steps_now - J.seen_steps)));
+    J.seen_steps = steps_now;
+  }
+  J.done = snap.done;
+  J.seen_pivots = snap.it_cnt;
+  J.try_fused = (snap.phase == PH_PRIMAL2);
+  if (J.done == D_NEED_PHASE1) {
+    snap.done = D_RUN;
+    snap.phase = PH_PHASE1;
+    snap.rc_base = nullptr;
+    snap.rc_out = sc.d_cost1;
+    *sc.h_ctl = snap;
+    upload_ctl(sc);
+    J.mode = SolveJob::PHASE1;
+    J.pb = 4;
+    return false;
+  }
+  if (J.done != D_RUN) {
+    J.mode = SolveJob::FINAL;
+    return false;
+  }
+  J.batch = std::min(J.batch * 2, 256);
+  return false;
+}
+
+static bool job_prepare(SolveJob &J, mvx_prob *P, const mvx_smcp *parm) {
+  J.P = P;
+  if (parm) J.parm = *parm;
+  else mvx_init_smcp(&J.parm);
+  if (P->m < 1 || P->n < 1) {
+    P->status = MVX_UNDEF;
+    J.rc = MVX_EFAIL;
+    return false;
+  }
+  if (!P->valid) build_slack_tableau(P);
+  return true;
+}
+
+int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
+  SolveJob J;
+  if (!job_prepare(J, P, parm)) return J.rc;
+  Context &c = ctx();
+  J.sc = &c.main;
+  job_begin(c, J);
+  for (;;) {
+    job_enqueue(c, J);
+    HIPCHECK(hipStreamSynchronize(J.sc->stream));
+    if (job_collect(c, J)) break;
+  }
+  return J.rc;
+}
+
+// ------------------------------------------------------------------------ batched solves
+// Independent node LPs (the two children of a branch, a window of open B&B nodes) advance together:
+// ONE launch of k_select / k_update carries every handle of the batch (grid.z = slot), each slot
+// with its own control block, scratch and staging area.  Small tableaux are bound by the dispatch
+// rate of tiny kernels (measured: 8 streams give only ~1.7x), so the slots share launches instead
+// of competing for them.  Results are bit-identical to one mvx_simplex call per handle: every
+// slot runs the same generic state machine (k_select) on its own data.
+struct BatchCtx {
+  int slots = 0;
+  int m_cap = 0, ld = 0; // per-slot scratch capacity
+  hipStream_t stream = nullptr;
+  Ctl *d_ctl = nullptr, *h_ctl = nullptr;
+  unsigned char *scratch = nullptr;
+  size_t scratch_stride = 0;
+  unsigned char *d_stage = nullptr, *h_stage = nullptr;
+  size_t stage_stride = 0;
+};
+static BatchCtx g_batch;
+static int g_batch_slots = 16;
+
+static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
+  if (!bc.stream) HIPCHECK(hipStreamCreateWithFlags(&bc.stream, hipStreamNonBlocking));
+  if (slots <= bc.slots && m_cap <= bc.m_cap && ld <= bc.ld) return;
+  HIPCHECK(hipStreamSynchronize(bc.stream));
+  if (bc.d_ctl) HIPCHECK(hipFree(bc.d_ctl));
+  if (bc.h_ctl) HIPCHECK(hipHostFree(bc.h_ctl));
+  if (bc.scratch) HIPCHECK(hipFree(bc.scratch));
+  if (bc.d_stage) HIPCHECK(hipFree(bc.d_stage));
+  if (bc.h_stage) HIPCHECK(hipHostFree(bc.h_stage));
+  bc.slots = std::max(slots, bc.slots);
+  bc.m_cap = std::max(m_cap, bc.m_cap);
+  bc.ld = std::max(ld, bc.ld);
+  HIPCHECK(hipMalloc((void **)&bc.d_ctl, sizeof(Ctl) * bc.slots));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_ctl, sizeof(Ctl) * bc.slots));
+  bc.scratch_stride = align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256);
+  HIPCHECK(hipMalloc((void **)&bc.scratch, bc.scratch_stride * bc.slots));
+  HIPCHECK(hipMemsetAsync(bc.scratch, 0, bc.scratch_stride * bc.slots, bc.stream));
+  bc.stage_stride = stage_size(bc.m_cap, bc.ld);
+  HIPCHECK(hipMalloc((void **)&bc.d_stage, bc.stage_stride * bc.slots));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_stage, bc.stage_stride * bc.slots));
+  // idle slots must read as finished
+  std::memset(bc.h_ctl, 0, sizeof(Ctl) * bc.slots);
+  for (int k = 0; k < bc.slots; k++) bc.h_ctl[k].done = D_FAIL;
+  HIPCHECK(hipMemcpyAsync(bc.d_ctl, bc.h_ctl, sizeof(Ctl) * bc.slots, hipMemcpyHostToDevice, bc.stream));
+}
+
+static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &parm) {
+  Ctl *h = &bc.h_ctl[k];
+  std::memset(h, 0, sizeof(Ctl));
+  unsigned char *sb = bc.scratch + (size_t)k * bc.scratch_stride;
+  h->T = P->d_T;
+  h->bvar = P->d_bvar; h->blb = P->d_blb; h->bub = P->d_bub;
+  h->nvar = P->d_nvar; h->nflag = P->d_nflag; h->nlb = P->d_nlb; h->nub = P->d_nub;
+  h->colq = (double *)sb;
+  h->srow = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256));
+  h->m = P->m; h->n = P->n; h->ld = P->ld; h->m_cap = P->m_cap;
+  h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
+  h->tol_bnd = parm.tol_bnd; h->tol_dj = parm.tol_dj; h->tol_piv = parm.tol_piv;
+  h->phase = PH_START; h->done = D_RUN; h->budget = parm.it_lim;
+  h->fstate = F_OFF;
+  HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], h, sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
+}
+
+// mirrors + status of a finished slot; layout inside the slot follows the handle's own m_cap / ld
+static int batch_finish_slot(BatchCtx &bc, int k, mvx_prob *P) {
+  const unsigned char *s = bc.h_stage + (size_t)k * bc.stage_stride;
+  Ctl snap;
+  std::memcpy(&snap, s, sizeof(Ctl));
+  const double *beta = (const double *)(s + sizeof(Ctl));
+  const double *dj = beta + (P->m_cap + 1);
+  const int *bv = (const int *)(dj + P->ld);
+  const int *nv = bv + (P->m_cap + 1);
+  const int *nf = nv + P->ld;
+  P->beta.assign(beta, beta + P->m + 1);
+  P->dj.assign(dj, dj + P->n + 1);
+  P->bvar.assign(bv, bv + P->m + 1);
+  P->nvar.assign(nv, nv + P->n + 1);
+  P->nflag.assign(nf, nf + P->n + 1);
+  rebuild_pos(P);
+  P->sol_fresh = true;
+  P->last_ms = 0.0;
   P->it_cnt += snap.it_cnt;
   P->hint_dual = false;
-  switch (done) {
+  switch (snap.done) {
     case D_OPT: P->status = MVX_OPT; return 0;
     case D_UNBND: P->status = MVX_UNBND; return 0;
     case D_NOFEAS: P->status = MVX_NOFEAS; return 0;
-    case D_ITLIM:
-      P->status = (snap.phase == PH_PRIMAL2) ? MVX_FEAS : MVX_INFEAS;
-      return MVX_EITLIM;
+    case D_ITLIM: P->status = (snap.phase == PH_PRIMAL2) ? MVX_FEAS : MVX_INFEAS; return MVX_EITLIM;
     default: P->status = MVX_UNDEF; return MVX_EFAIL;
   }
+}
+
+int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, int *rcs) {
+  if (count <= 0) return 0;
+  Context &c = ctx();
+  mvx_smcp parm;
+  if (parm_in) parm = *parm_in;
+  else mvx_init_smcp(&parm);
+  std::vector<int> pending, fallback;
+  int m_cap = 0, ld = 0, m_max = 0, n_max = 0;
+  for (int i = 0; i < count; i++) {
+    mvx_prob *P = probs[i];
+    if (P->m < 1 || P->n < 1) {
+      P->status = MVX_UNDEF;
+      if (rcs) rcs[i] = MVX_EFAIL;
+      continue;
+    }
+    if (!P->valid) build_slack_tableau(P);
+    pending.push_back(i);
+    m_cap = std::max(m_cap, P->m_cap);
+    ld = std::max(ld, P->ld);
+    m_max = std::max(m_max, P->m);
+    n_max = std::max(n_max, P->n);
+  }
+  if (pending.size() == 1) { // nothing to share a launch with
+    const int i = pending[0];
+    const int rc = engine_simplex(probs[i], &parm);
+    if (rcs) rcs[i] = rc;
+    return 0;
+  }
+  if (pending.empty()) return 0;
+  BatchCtx &bc = g_batch;
+  const int K = std::min((int)pending.size(), g_batch_slots);
+  ensure_batch(bc, K, m_cap, ld);
+  // edits queued on the main stream (bound changes, clones) must be visible to the batch stream
+  HIPCHECK(hipStreamSynchronize(c.main.stream));
+  std::vector<int> slot((size_t)bc.slots, -1);
+  size_t next = 0;
+  int active = 0;
+  for (int k = 0; k < K && next < pending.size(); k++) {
+    slot[(size_t)k] = pending[next++];
+    batch_fill_slot(bc, k, probs[slot[(size_t)k]], parm);
+    active++;
+  }
+  int depth = 8;
+  while (active > 0) {
+    for (int d = 0; d < depth; d++) {
+      launch_select(bc.d_ctl, bc.stream, K);
+      launch_update(bc.d_ctl, m_max, n_max, bc.stream, K);
+    }
+    launch_export(bc.d_ctl, bc.d_stage, m_max, n_max, 0, bc.stream, K, bc.stage_stride);
+    HIPCHECK(hipMemcpyAsync(bc.h_stage, bc.d_stage, bc.stage_stride * K, hipMemcpyDeviceToHost, bc.stream));
+    HIPCHECK(hipStreamSynchronize(bc.stream));
+    for (int k = 0; k < K; k++) {
+      const int i = slot[(size_t)k];
+      if (i < 0) continue;
+      Ctl snap;
+      std::memcpy(&snap, bc.h_stage + (size_t)k * bc.stage_stride, sizeof(Ctl));
+      if (snap.done == D_RUN) continue;
+      if (snap.done == D_NEED_PHASE1) {
+        fallback.push_back(i); // neither primal nor dual feasible: finish on the single-handle path
+        probs[i]->it_cnt += snap.it_cnt;
+      } else {
+        const int rc = batch_finish_slot(bc, k, probs[i]);
+        if (rcs) rcs[i] = rc;
+      }
+      active--;
+      slot[(size_t)k] = -1;
+      if (next < pending.size()) {
+        slot[(size_t)k] = pending[next++];
+        batch_fill_slot(bc, k, probs[slot[(size_t)k]], parm);
+        active++;
+      } else {
+        bc.h_ctl[k].done = D_FAIL; // idle
+        bc.h_ctl[k].T = nullptr;
+        HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], &bc.h_ctl[k], sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
+      }
+    }
+    depth = std::min(depth * 2, 64);
+  }
+  for (int i : fallback) {
+    // the batch left this handle untouched apart from zero or more completed pivots
+    probs[i]->sol_fresh = false;
+    const int rc = engine_simplex(probs[i], &parm);
+    if (rcs) rcs[i] = rc;
+  }
+  return 0;
 }
 
 // -------------------------------------------------------------------------- model edits
 void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old_ub, double lb, double ub) {
   if (!P->valid) return;
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   const int pos = P->pos[k];
   if (pos > 0) {
-    launch_set_basic_bounds(P->d_blb, P->d_bub, pos, lb, ub, c.stream);
+    launch_set_basic_bounds(P->d_blb, P->d_bub, pos, lb, ub, sc.stream);
     P->hint_dual = true; // a basic variable's bound moved: the warm start is a dual one (bs.cpp:274,282)
   } else {
     const int jj = -pos;
@@ -615,9 +944,9 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
       default: flag = MVX_NS; break;
     }
     P->nflag[jj] = flag;
-    launch_set_nonbasic(P->d_nlb, P->d_nub, P->d_nflag, jj, lb, ub, flag, c.stream);
+    launch_set_nonbasic(P->d_nlb, P->d_nub, P->d_nflag, jj, lb, ub, flag, sc.stream);
     const double xn = nb_value(flag, lb, ub);
-    if (xn != xo) launch_shift_nonbasic(P->d_T, P->ld, P->m, jj, xn - xo, c.stream);
+    if (xn != xo) launch_shift_nonbasic(P->d_T, P->ld, P->m, jj, xn - xo, sc.stream);
   }
   P->sol_fresh = false;
   P->status = MVX_UNDEF;
@@ -626,8 +955,10 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
 void engine_add_rows(mvx_prob *P, int first, int nrs) {
   if (!P->valid) return;
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   grow_rows(P, P->m);
-  launch_add_rows(P->d_T, P->ld, P->n, P->d_bvar, P->d_blb, P->d_bub, P->d_nvar, first, nrs, P->m, c.stream);
+  launch_add_rows(P->d_T, P->ld, P->n, P->d_bvar, P->d_blb, P->d_bub, P->d_nvar, first, nrs, P->m, sc.stream);
   // host mirrors
   for (int i = 1; i < first; i++)
     if (P->bvar[i] >= first) P->bvar[i] += nrs;
@@ -643,16 +974,18 @@ void engine_add_rows(mvx_prob *P, int first, int nrs) {
 // run k_rowcomb with host-provided weights / base, writing row `dst_row` of the tableau
 static void rowcomb_into_row(mvx_prob *P, const std::vector<double> &w, const std::vector<double> &base, int dst_row) {
   Context &c = ctx();
-  ensure_scratch(c, P->m_cap, P->ld);
-  HIPCHECK(hipStreamSynchronize(c.stream)); // h_ctl / pageable sources below must not be in flight
-  fill_ctl(c, P, c.h_ctl);
-  c.h_ctl->rc_base = c.d_rcbase;
-  c.h_ctl->rc_out = P->d_T + (size_t)dst_row * P->ld;
-  upload_ctl(c);
-  HIPCHECK(hipMemcpyAsync(c.d_wts, w.data(), (size_t)(P->m + 1) * 8, hipMemcpyHostToDevice, c.stream));
-  HIPCHECK(hipMemcpyAsync(c.d_rcbase, base.data(), (size_t)(P->n + 1) * 8, hipMemcpyHostToDevice, c.stream));
-  launch_rowcomb(c.d_ctl, P->m, P->n, 0, c.stream);
-  HIPCHECK(hipStreamSynchronize(c.stream));
+  SolveCtx &sc = c.main;
+  (void)sc;
+  ensure_scratch(sc, P->m_cap, P->ld);
+  HIPCHECK(hipStreamSynchronize(sc.stream)); // h_ctl / pageable sources below must not be in flight
+  fill_ctl(sc, P, sc.h_ctl);
+  sc.h_ctl->rc_base = sc.d_rcbase;
+  sc.h_ctl->rc_out = P->d_T + (size_t)dst_row * P->ld;
+  upload_ctl(sc);
+  HIPCHECK(hipMemcpyAsync(sc.d_wts, w.data(), (size_t)(P->m + 1) * 8, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(sc.d_rcbase, base.data(), (size_t)(P->n + 1) * 8, hipMemcpyHostToDevice, sc.stream));
+  launch_rowcomb(sc.d_ctl, P->m, P->n, 0, sc.stream);
+  HIPCHECK(hipStreamSynchronize(sc.stream));
 }
 
 void engine_row_from_model(mvx_prob *P, int i) {
@@ -717,30 +1050,36 @@ void engine_copy(mvx_prob *dst, const mvx_prob *src) {
     return;
   }
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   void *slab = slab_alloc(c, src->slab_bytes);
   bind_slab(dst, slab, src->m_cap, src->ld);
   // only the live rows of T need to travel; the small arrays follow T in one contiguous tail
   SlabLayout L = slab_layout(src->m_cap, src->ld);
-  HIPCHECK(hipMemcpyAsync(dst->d_T, src->d_T, (size_t)(src->m + 1) * src->ld * 8, hipMemcpyDeviceToDevice, c.stream));
+  HIPCHECK(hipMemcpyAsync(dst->d_T, src->d_T, (size_t)(src->m + 1) * src->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
   HIPCHECK(hipMemcpyAsync((unsigned char *)slab + L.o_bvar, (const unsigned char *)src->slab + L.o_bvar, L.total - L.o_bvar,
-                          hipMemcpyDeviceToDevice, c.stream));
+                          hipMemcpyDeviceToDevice, sc.stream));
   dst->valid = true;
 }
 
 int engine_get_tableau(const mvx_prob *P, double *out) {
   if (!P->valid) return -1;
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   HIPCHECK(hipMemcpy2DAsync(out, (size_t)(P->n + 1) * 8, P->d_T, (size_t)P->ld * 8, (size_t)(P->n + 1) * 8, (size_t)P->m + 1,
-                            hipMemcpyDeviceToHost, c.stream));
-  HIPCHECK(hipStreamSynchronize(c.stream));
+                            hipMemcpyDeviceToHost, sc.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
   return 0;
 }
 
 int engine_get_row(const mvx_prob *P, int row, double *out) {
   if (!P->valid) return -1;
   Context &c = ctx();
-  HIPCHECK(hipMemcpyAsync(out, P->d_T + (size_t)row * P->ld, (size_t)(P->n + 1) * 8, hipMemcpyDeviceToHost, c.stream));
-  HIPCHECK(hipStreamSynchronize(c.stream));
+  SolveCtx &sc = c.main;
+  (void)sc;
+  HIPCHECK(hipMemcpyAsync(out, P->d_T + (size_t)row * P->ld, (size_t)(P->n + 1) * 8, hipMemcpyDeviceToHost, sc.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
   return 0;
 }
 
@@ -771,6 +1110,8 @@ long long engine_pack_size(const mvx_prob *P) {
 
 int engine_pack(const mvx_prob *P, void *dev_buf) {
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   const int m = P->m, n = P->n;
   const size_t hb = pack_host_bytes(m, n);
   std::vector<unsigned char> host(hb, 0);
@@ -796,30 +1137,32 @@ int engine_pack(const mvx_prob *P, void *dev_buf) {
   put(P->rlb.data(), 8 * (size_t)(m + 1));
   put(P->rub.data(), 8 * (size_t)(m + 1));
   unsigned char *d = (unsigned char *)dev_buf;
-  HIPCHECK(hipMemcpyAsync(d, host.data(), hb, hipMemcpyHostToDevice, c.stream));
+  HIPCHECK(hipMemcpyAsync(d, host.data(), hb, hipMemcpyHostToDevice, sc.stream));
   if (P->valid) {
     SlabLayout L = slab_layout(P->m_cap, P->ld);
     const size_t tb = (size_t)(m + 1) * P->ld * 8;
-    HIPCHECK(hipMemcpyAsync(d + hb, P->d_T, tb, hipMemcpyDeviceToDevice, c.stream));
+    HIPCHECK(hipMemcpyAsync(d + hb, P->d_T, tb, hipMemcpyDeviceToDevice, sc.stream));
     HIPCHECK(hipMemcpyAsync(d + hb + align_up(tb, 256), (const unsigned char *)P->slab + L.o_bvar, L.total - L.o_bvar,
-                            hipMemcpyDeviceToDevice, c.stream));
+                            hipMemcpyDeviceToDevice, sc.stream));
   }
-  HIPCHECK(hipStreamSynchronize(c.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
   return 0;
 }
 
 // dst must already hold a copy of the receiver's root MODEL (rows, objective, kinds)
 int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   const unsigned char *d = (const unsigned char *)dev_buf;
   PackHdr h;
-  HIPCHECK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c.stream));
-  HIPCHECK(hipStreamSynchronize(c.stream));
+  HIPCHECK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, sc.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
   if (h.magic != PACK_MAGIC || h.m != dst->m || h.n != dst->n) return -1;
   const int m = (int)h.m, n = (int)h.n;
   std::vector<unsigned char> host((size_t)h.host_bytes);
-  HIPCHECK(hipMemcpyAsync(host.data(), d, (size_t)h.host_bytes, hipMemcpyDeviceToHost, c.stream));
-  HIPCHECK(hipStreamSynchronize(c.stream));
+  HIPCHECK(hipMemcpyAsync(host.data(), d, (size_t)h.host_bytes, hipMemcpyDeviceToHost, sc.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
   const unsigned char *b = host.data() + sizeof(PackHdr);
   const unsigned char *b0 = b;
   auto get = [&](void *dstp, size_t bytes) {
@@ -852,10 +1195,10 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
     void *slab = slab_alloc(c, L.total);
     bind_slab(dst, slab, (int)h.m_cap, (int)h.ld);
     const size_t tb = (size_t)(m + 1) * dst->ld * 8;
-    HIPCHECK(hipMemcpyAsync(dst->d_T, d + h.host_bytes, tb, hipMemcpyDeviceToDevice, c.stream));
+    HIPCHECK(hipMemcpyAsync(dst->d_T, d + h.host_bytes, tb, hipMemcpyDeviceToDevice, sc.stream));
     HIPCHECK(hipMemcpyAsync((unsigned char *)slab + L.o_bvar, d + h.host_bytes + align_up(tb, 256), L.total - L.o_bvar,
-                            hipMemcpyDeviceToDevice, c.stream));
-    HIPCHECK(hipStreamSynchronize(c.stream));
+                            hipMemcpyDeviceToDevice, sc.stream));
+    HIPCHECK(hipStreamSynchronize(sc.stream));
     rebuild_pos(dst);
     dst->valid = true;
   }
@@ -866,14 +1209,18 @@ void tuning(int tr, int hot, int nt) {
   sync_stream();
   set_tuning(tr, hot, nt);
   if (g_ctx) { // partial-buffer sizes depend on the row-block depth
-    g_ctx->sc_m_cap = 0;
-    g_ctx->sc_ld = 0;
+    g_ctx->main.sc_m_cap = 0;
+    g_ctx->main.sc_ld = 0;
+    for (SolveCtx *x : g_ctx->pool) x->sc_m_cap = x->sc_ld = 0;
   }
 }
 
+void use_graphs(int on) { g_use_graphs = on != 0; }
 void profile_enable(int on) { ctx().prof = on != 0; }
 void profile_reset() {
   Context &c = ctx();
+  SolveCtx &sc = c.main;
+  (void)sc;
   c.prof_update_ms = 0.0;
   c.prof_update_n = 0;
 }

@@ -10,6 +10,7 @@ void sync_stream();
 
 // solve (glp_simplex)
 int engine_simplex(mvx_prob *P, const mvx_smcp *parm);
+int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm, int *rcs);
 
 // tableau maintenance under model edits; all no-ops while !P->valid
 void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old_ub, double lb, double ub);
@@ -30,6 +31,7 @@ long long engine_pack_size(const mvx_prob *P);
 int engine_pack(const mvx_prob *P, void *dev_buf);
 int engine_unpack(mvx_prob *dst, const void *dev_buf);
 void tuning(int tr, int hot, int nt);
+void use_graphs(int on);
 void profile_enable(int on);
 void profile_reset();
 double profile_update_ms();

@@ -254,6 +254,7 @@ __device__ __forceinline__ void dev_finish(Ctl *c, int code, int phase, int roun
 // Device-side restatement of orc_simplex's round loop + one pricing / ratio-test step.
 __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
   __shared__ Cand lds[17];
+  c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
   if (c->done != D_RUN) return;
   int phase = c->phase, rounds = c->rounds;
   int p = 0, p_up = 0, q = 0, sdir = 0, kind = 0; // kind 1 primal, 2 dual
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
 // Block = 256 lanes x 2 columns (16 B per lane, 4 KB per row segment), TR rows deep.
 template <int TR>
 __global__ __launch_bounds__(256) void k_update(Ctl *c) {
+  c += blockIdx.z;
   if (c->done != D_RUN || c->step != ST_PIVOT) return;
   const int m = c->m, n = c->n, p = c->p, q = c->q;
   const size_t ld = (size_t)c->ld;
@@ -511,9 +513,12 @@ __global__ __launch_bounds__(256) void k_add_rows(double *T, int ld, int n, int 
 // ---------------------------------------------------------------------------- k_export
 // Pack what the host needs after a solve into one staging buffer:
 //   [Ctl][beta (m_cap+1) f64][d (ld) f64][bvar (m_cap+1) i32][nvar (ld) i32][nflag (ld) i32]
-__global__ __launch_bounds__(256) void k_export(Ctl *c, unsigned char *stage, int force) {
+__global__ __launch_bounds__(256) void k_export(Ctl *c, unsigned char *stage, int force, size_t slot_stride) {
+  c += blockIdx.z;
+  stage += (size_t)blockIdx.z * slot_stride;
   const int t = (int)blockIdx.x * 256 + TIDX;
   if (t == 0) *reinterpret_cast<Ctl *>(stage) = *c;
+  if (c->T == nullptr) return; // idle slot of a batched launch
   if (!force && c->done == D_RUN) return;
   const int m = c->m, n = c->n, ld = c->ld, mc = c->m_cap;
   double *beta = reinterpret_cast<double *>(stage + sizeof(Ctl));
@@ -943,10 +948,10 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
 #undef FB_CASE
   std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
 }
-void launch_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, s, d_ctl); }
-void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s) {
+void launch_select(Ctl *d_ctl, hipStream_t s, int slots) { hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl); }
+void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
   const int pairs = (n + 2) / 2;
-  dim3 grid((pairs + 255) / 256, (m + 1 + UPDATE_TR - 1) / UPDATE_TR);
+  dim3 grid((pairs + 255) / 256, (m + 1 + UPDATE_TR - 1) / UPDATE_TR, slots);
   hipLaunchKernelGGL(k_update<UPDATE_TR>, grid, dim3(256), 0, s, d_ctl);
 }
 void launch_p1_head(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_head, dim3(1), dim3(1024), 0, s, d_ctl); }
@@ -971,9 +976,9 @@ void launch_add_rows(double *T, int ld, int n, int *bvar, double *blb, double *b
   int span = (n > m_new ? n : m_new) + 1;
   hipLaunchKernelGGL(k_add_rows, dim3((span + 255) / 256), dim3(256), 0, s, T, ld, n, bvar, blb, bub, nvar, first, nrs);
 }
-void launch_export(Ctl *d_ctl, unsigned char *stage, int m, int n, int force, hipStream_t s) {
+void launch_export(Ctl *d_ctl, unsigned char *stage, int m, int n, int force, hipStream_t s, int slots, size_t slot_stride) {
   int span = (n > m ? n : m) + 1;
-  hipLaunchKernelGGL(k_export, dim3((span + 255) / 256), dim3(256), 0, s, d_ctl, stage, force);
+  hipLaunchKernelGGL(k_export, dim3((span + 255) / 256, 1, slots), dim3(256), 0, s, d_ctl, stage, force, slot_stride);
 }
 
 } // namespace mvx

@@ -73,6 +73,15 @@ class HipNodeEngine:
     def print_info(self, prob, quirks):
         return self._bnb.print_info(prob, quirks=quirks, table=self.table)
 
+    def solve_many(self, probs):
+        """Independent handles solved concurrently (mvx_simplex_batch: one HIP stream each)."""
+        if not probs:
+            return
+        import ctypes as C
+
+        arr = (C.c_void_p * len(probs))(*[p.h for p in probs])
+        self.api.simplex_batch(arr, len(probs), None, None)
+
     def pack(self, prob):
         n = self.api.pack_size(prob.h)
         t = torch.empty(n, dtype=torch.uint8, device=self.device)
@@ -163,13 +172,15 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         # ---- A. solve the window (bs.cpp:114-117, printInfo bs.cpp:135|151)
         A = torch.full((W, 6), NEG_INF, dtype=torch.float64)
         solved = {}
+        mine = []
         for w, nd in enumerate(window):
             if nd.owner != rank:
                 continue
             a = api.create()
             api.copy_prob(a.h, local[nd.oid].h, capi.OFF)
-            before = a.it_cnt
-            a.simplex()
+            mine.append((w, nd, a, a.it_cnt))
+        engine.solve_many([a for (_, _, a, _) in mine])
+        for w, nd, a, before in mine:
             st, viol = engine.print_info(a, quirks)
             acc = 0.0
             for i in viol:
@@ -237,6 +248,7 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         # ---- C. owners create and solve the children (bs.cpp:269-288)
         C = torch.full((max(1, len(branch_list)), 4), NEG_INF, dtype=torch.float64)
         fresh = {}
+        made = []
         for k, (nd, s2, s3, pick, ev) in enumerate(branch_list):
             if nd.owner != rank:
                 continue
@@ -245,24 +257,21 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
             S2, S3 = a.copy(capi.ON), a.copy(capi.ON)
             if quirks:
                 api.set_col_bnds(S2.h, pick, capi.UP, 0.0, math.floor(bnd))  # bs.cpp:274
+                api.set_col_bnds(S3.h, pick, capi.LO, math.ceil(bnd), 0.0)  # bs.cpp:282
             else:
-                t, l = api.get_col_type(a.h, pick), api.get_col_lb(a.h, pick)
+                t, l, u = api.get_col_type(a.h, pick), api.get_col_lb(a.h, pick), api.get_col_ub(a.h, pick)
                 if t in (capi.LO, capi.DB, capi.FX):
                     api.set_col_bnds(S2.h, pick, capi.FX if l == math.floor(bnd) else capi.DB, l, math.floor(bnd))
                 else:
                     api.set_col_bnds(S2.h, pick, capi.UP, 0.0, math.floor(bnd))
-            b2 = S2.it_cnt
-            S2.simplex()  # bs.cpp:279
-            if quirks:
-                api.set_col_bnds(S3.h, pick, capi.LO, math.ceil(bnd), 0.0)  # bs.cpp:282
-            else:
-                t, u = api.get_col_type(a.h, pick), api.get_col_ub(a.h, pick)
                 if t in (capi.UP, capi.DB, capi.FX):
                     api.set_col_bnds(S3.h, pick, capi.FX if u == math.ceil(bnd) else capi.DB, math.ceil(bnd), u)
                 else:
                     api.set_col_bnds(S3.h, pick, capi.LO, math.ceil(bnd), 0.0)
-            b3 = S3.it_cnt
-            S3.simplex()  # bs.cpp:287
+            made.append((k, s2, s3, S2, S3, S2.it_cnt, S3.it_cnt))
+        # every child of this round is an independent LP (bs.cpp:279,287): solve them together
+        engine.solve_many([p for (_, _, _, S2, S3, _, _) in made for p in (S2, S3)])
+        for k, s2, s3, S2, S3, b2, b3 in made:
             C[k] = torch.tensor([S2.obj, S3.obj, float((S2.it_cnt - b2) + (S3.it_cnt - b3)), float(api.pack_size(S2.h))], dtype=torch.float64)
             fresh[s2], fresh[s3] = S2, S3
         C = allreduce_max(C.to(cdev))

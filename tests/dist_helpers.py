@@ -27,6 +27,10 @@ class OracleNodeEngine:
     def print_info(self, prob, quirks):
         return self._bnb.print_info(prob, quirks=quirks, table=self.table)
 
+    def solve_many(self, probs):
+        for p in probs:
+            p.simplex()
+
     def pack(self, prob):
         n = self.api.pack_size(prob.h)
         buf = np.zeros(n, dtype=np.uint8)

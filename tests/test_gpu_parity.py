@@ -182,3 +182,75 @@ def test_infeasible_and_unbounded(gpu, orc):
         P.load_general(A, [(UP, 0.0, 1.0)], cols, np.array([1.0, 0.0]), direction=MAX)
         P.simplex()
         assert P.status == capi.UNBND
+
+
+def test_batch_solve_equals_sequential(gpu, orc):
+    """mvx_simplex_batch: a window of independent node LPs on separate streams, same bits as one by one."""
+    import ctypes as C
+
+    A, b, c, U = synth.dense_ilp(24, 48, seed=6, U=2)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        P.simplex()
+    x = o.col_prim()
+    frac = [j + 1 for j in range(len(x)) if np.trunc(x[j]) != x[j]]
+    kids_g, kids_o = [], []
+    for j in frac[:6]:
+        for (t, lo, hi) in ((UP, 0.0, float(np.floor(x[j - 1]))), (LO, float(np.ceil(x[j - 1])), 0.0)):
+            for P, kids in ((g, kids_g), (o, kids_o)):
+                ch = P.copy()
+                P.api.set_col_bnds(ch.h, j, t, lo, hi)
+                kids.append(ch)
+    # a fresh (never solved) dense LP rides along: exercises tableau build + the primal fast path in a batch
+    A2, b2, c2 = synth.dense_lp(40, 90, 9)
+    for api, kids in ((gpu, kids_g), (orc, kids_o)):
+        Q = api.create()
+        Q.load_dense(A2, b2, c2)
+        kids.append(Q)
+    arr = (C.c_void_p * len(kids_g))(*[k.h for k in kids_g])
+    rcs = (C.c_int * len(kids_g))()
+    assert gpu.simplex_batch(arr, len(kids_g), None, rcs) == 0
+    for k in kids_o:
+        k.simplex()
+    assert len(kids_g) >= 9
+    for kg, ko, rc in zip(kids_g, kids_o, rcs):
+        assert rc == 0
+        assert_same_state(kg, ko, "batched child")
+
+
+def test_batch_mixed_shapes_phase1_and_limits(gpu, orc):
+    """One batched launch carrying handles of different shapes, a phase-1 start (falls back to the
+    single-handle path), an infeasible LP, an iteration limit and more handles than slots."""
+    import ctypes as C
+
+    rng = np.random.default_rng(21)
+    specs = []
+    for k in range(40):
+        specs.append(("gen", lpgen.random_general_lp(rng)))
+    for (m, n, seed) in [(5, 9, 1), (33, 70, 2), (64, 40, 3), (120, 200, 4)]:
+        specs.append(("dense", synth.dense_lp(m, n, seed)))
+    pairs = []
+    for kind, sp in specs:
+        hs = []
+        for api in (gpu, orc):
+            P = api.create()
+            if kind == "gen":
+                A, row_b, col_b, c, direction = sp
+                P.load_general(A, row_b, col_b, c, c0=0.5, direction=direction)
+            else:
+                P.load_dense(*sp)
+            hs.append(P)
+        pairs.append(hs)
+    arr = (C.c_void_p * len(pairs))(*[g.h for g, _ in pairs])
+    rcs = (C.c_int * len(pairs))()
+    parm = capi.Smcp()
+    gpu.init_smcp(C.byref(parm))
+    parm.it_lim = 25
+    assert gpu.simplex_batch(arr, len(pairs), C.byref(parm), rcs) == 0
+    seen = set()
+    for (g, o), rc in zip(pairs, rcs):
+        assert o.simplex(it_lim=25) == rc
+        assert_same_state(g, o, "mixed batch")
+        seen.add(g.status)
+    assert {capi.OPT, capi.UNBND} <= seen and capi.FEAS in seen  # FEAS: the 120x200 LP hit the limit
