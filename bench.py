@@ -82,8 +82,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--rows", type=int, default=4096, help="constraints m of the dense LP")
+    ap.add_argument("--cols", type=int, default=8192, help="columns n of the dense LP")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=100, help="extra pivots timed per-kernel with HIP events")
@@ -100,18 +100,25 @@ def main():
 
     mvolps_amd.require_device()
     api = mvolps_amd.api()
-    if api.set_device(local_rank) != 0:
-        raise SystemExit("cannot bind device %d" % local_rank)
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a one-GPU box only: MVX_BENCH_REHEARSAL=1 puts every rank on device 0 and uses
+    # gloo for the barrier / MAX-reduce, to exercise the multi-rank code path without N GPUs
+    rehearsal = os.environ.get("MVX_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    if api.set_device(dev_index) != 0:
+        raise SystemExit("cannot bind device %d" % dev_index)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
 
     from mvolps_amd import synth
 
-    m, n = args.m, args.n
+    m, n = args.rows, args.cols
     A, b, c = synth.dense_lp(m, n, args.seed + rank)
     P = api.create()
     P.load_dense(A, b, c)
@@ -136,7 +143,7 @@ def main():
     device_ms = api.last_solve_ms(P.h)
 
     # max over ranks
-    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el_max = float(t.item())
@@ -196,7 +203,7 @@ def main():
             "device_ms_per_step": device_ms / args.steps,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(m, n, args.seed)
         print(json.dumps(out), flush=True)
     if dist is not None:
