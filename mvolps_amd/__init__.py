@@ -34,6 +34,14 @@ _api = None
 
 def load_library():
     """dlopen the engine; raises if it has not been built (python -m mvolps_amd.build)."""
+    # torch bundles its own HIP runtime; whichever libamdhip64 is loaded first serves the whole
+    # process, and torch cannot find the GPU when it is not its own.  Load torch's first so that
+    # the engine, torch.cuda and torch.distributed (RCCL) share one runtime.
+    if os.environ.get("MVX_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libmvolps_amd.so is missing (%s): build it with `python -m mvolps_amd.build`; "

@@ -923,18 +923,20 @@ constexpr int UPDATE_TR = 16;
 // tuning knobs of the streamed update (mvx_set_tuning; defaults are the measured best)
 static int g_tr = 0, g_hot = 1, g_nt = 0; // g_tr 0 = pick from the grid size
 void set_tuning(int tr, int hot, int nt) {
-  g_tr = (tr == 8 || tr == 16 || tr == 32) ? tr : 0;
+  g_tr = (tr == 4 || tr == 8 || tr == 16 || tr == 32) ? tr : 0;
   g_hot = hot ? 1 : 0;
   g_nt = nt ? 1 : 0;
 }
 // row-block depth: 16 rows per block once that still gives every CU several blocks, else 8
 static int pick_tr(int m, int n) {
   if (g_tr) return g_tr;
-  const long blocks16 = (long)((m + 15) / 16) * (((n + 2) / 2 + 255) / 256);
-  return blocks16 >= 2048 ? 16 : 8;
+  const long tiles = ((n + 2) / 2 + 255) / 256;
+  if ((long)((m + 15) / 16) * tiles >= 2048) return 16;
+  if ((long)((m + 7) / 8) * tiles >= 2048) return 8;
+  return 4;
 }
 int fused_npb(int n) { return (n + 1 + 255) / 256; }
-int fused_nrb_max(int m) { return (m + 7) / 8; }
+int fused_nrb_max(int m) { return (m + 3) / 4; }
 void launch_fboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fboot, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
 void launch_fa(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fa, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
 void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
@@ -945,6 +947,7 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
   if (tr == TR_ && g_hot == HOT_ && g_nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
   FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
   FB_CASE(8, 0, 0) FB_CASE(32, 0, 0) FB_CASE(8, 0, 1) FB_CASE(16, 0, 1) FB_CASE(32, 0, 1)
+  FB_CASE(4, 1, 0) FB_CASE(4, 0, 0) FB_CASE(4, 1, 1) FB_CASE(4, 0, 1)
 #undef FB_CASE
   std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
 }
