@@ -254,3 +254,39 @@ def test_batch_mixed_shapes_phase1_and_limits(gpu, orc):
         assert_same_state(g, o, "mixed batch")
         seen.add(g.status)
     assert {capi.OPT, capi.UNBND} <= seen and capi.FEAS in seen  # FEAS: the 120x200 LP hit the limit
+
+
+@pytest.mark.parametrize("tr,hot,nt", [(4, 1, 0), (8, 1, 0), (16, 1, 0), (32, 1, 0), (16, 0, 0), (8, 1, 1)])
+def test_every_update_variant_is_bit_exact(gpu, orc, tr, hot, nt):
+    """All instantiations of the streamed update (row-block depth, batched loads, non-temporal access)
+    on a ragged shape, against the oracle, pivot for pivot; then the default selection again."""
+    A, b, c = synth.dense_lp(301, 1031, 77)
+    o = orc.create()
+    o.load_dense(A, b, c)
+    try:
+        gpu.set_tuning(tr, hot, nt)
+        g = gpu.create()
+        g.load_dense(A, b, c)
+        for lim in (1, 2, 37):
+            assert g.simplex(it_lim=lim) == o.simplex(it_lim=lim)
+            assert np.array_equal(g.tableau(), o.tableau()), (tr, hot, nt, lim)
+        g.simplex()
+        o.simplex()
+        assert_same_state(g, o, "variant %s" % ((tr, hot, nt),))
+    finally:
+        gpu.set_tuning(0, 1, 0)
+
+
+def test_large_grid_first_pivots_bit_exact(gpu, orc):
+    """The 16-row-deep tiles the 4096x8192 headline runs with (>= 2048 workgroups), checked bitwise
+    against the oracle on the first pivots of a 2048x8192 LP (the full solve is checked against the
+    HiGHS golden in test_gpu_golden.py)."""
+    A, b, c = synth.dense_lp(2048, 8192, 4242)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+    for lim in (3, 21):
+        assert g.simplex(it_lim=lim) == o.simplex(it_lim=lim) == capi.EITLIM
+        for x, y in zip(g.basis(), o.basis()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(g.tableau(), o.tableau())
