@@ -115,6 +115,16 @@ int mvx_printInfo(const mvx_lp_api *api, const void *prob, int quirks, int *viol
 /* CutContainer generateCut3(glp_prob*, int j)  gmi.h:7; inds/vals hold n+1 entries, returns -1 when rejected */
 int mvx_generateCut3(const mvx_lp_api *api, const void *prob, int j, int *inds, double *vals, double *lb);
 
+/* ---- node-level helpers for window drivers (mvolps_amd/dist_bnb.py): one call per node instead of
+   one per query.  Same arithmetic, same order as the loop body of bs.cpp. ---- */
+/* classification of a solved node (bs.cpp:135-156,227-241,260): out[0] status -1/0/1 (printInfo),
+   out[1] objective, out[2] number of violated columns, out[3] sum of their fractional parts,
+   out[4] pickVar's choice (0 when none), `root` = ParameterObj::_prob */
+int mvx_bnb_classify(const mvx_lp_api *api, const void *prob, const void *root, int quirks, int var_strat, double *out);
+/* bs.cpp:261-282: bound = col_prim(a, pick); S2/S3 = clones of `a` (created by the caller with
+   create_prob) with the branching bounds set; they are NOT solved here (the caller batches them) */
+int mvx_bnb_make_children(const mvx_lp_api *api, const void *a, int pick, int quirks, void *S2, void *S3);
+
 /* ---- callers and data formats either side of the path ---- */
 /* glp_read_lp(prob, NULL, fname) util.cpp:284 -- CPLEX LP format; 0 on success */
 int mvx_read_lp(mvx_prob *P, const void *parm, const char *fname);

@@ -90,6 +90,10 @@ def _bind(lib):
     lib.mvx_getFract.argtypes = [C.c_double]
     lib.mvx_printInfo.restype = C.c_int
     lib.mvx_printInfo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mvx_bnb_classify.restype = C.c_int
+    lib.mvx_bnb_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.mvx_bnb_make_children.restype = C.c_int
+    lib.mvx_bnb_make_children.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.mvx_generateCut3.restype = C.c_int
     lib.mvx_generateCut3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return lib
@@ -168,3 +172,19 @@ def generate_cut3(prob, j, table=None):
     if rc != 0:
         return None
     return inds, vals, lb.value
+
+
+def classify(prob, root, quirks=1, var_strat=0, table=None):
+    """(status, objective, n_violated, sum_fract, pick) of a solved node in one call."""
+    out = (C.c_double * 5)()
+    tptr = C.cast(C.pointer(table), C.c_void_p) if table is not None else None
+    lib().mvx_bnb_classify(tptr, prob.h, root.h, quirks, var_strat, out)
+    return int(out[0]), out[1], int(out[2]), out[3], int(out[4])
+
+
+def make_children(a, pick, quirks=1, table=None):
+    """The two branching clones of bs.cpp:269-282 (bounds set, not yet solved)."""
+    S2, S3 = a.api.create(), a.api.create()
+    tptr = C.cast(C.pointer(table), C.c_void_p) if table is not None else None
+    lib().mvx_bnb_make_children(tptr, a.h, pick, quirks, S2.h, S3.h)
+    return S2, S3

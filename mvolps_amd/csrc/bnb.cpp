@@ -496,6 +496,47 @@ void mvx_bnb_free_result(mvx_bnb_result *res) {
 
 double mvx_getFract(double x) { return getFract(x); }
 
+int mvx_bnb_classify(const mvx_lp_api *api, const void *prob, const void *root, int quirks, int var_strat, double *out) {
+  if (!api) api = &g_hip_api;
+  auto ret = printInfo(api, prob, quirks != 0);
+  mvx_bnb_params p;
+  mvx_bnb_default_params(&p);
+  p.var_strat = var_strat;
+  MVOLP::ParameterObj params(api, root, p);
+  double acc = 0;
+  for (int i : ret.second)
+    if (i != 0) acc += getFract(api->get_col_prim(prob, i)); // bs.cpp:229-233
+  out[0] = (double)ret.first;
+  out[1] = api->get_obj_val(prob);
+  out[2] = (double)ret.second.size();
+  out[3] = acc;
+  out[4] = ret.second.empty() ? 0.0 : (double)params.pickVar(ret.second);
+  return 0;
+}
+
+int mvx_bnb_make_children(const mvx_lp_api *api, const void *a, int pick, int quirks, void *S2, void *S3) {
+  if (!api) api = &g_hip_api;
+  const double bound = api->get_col_prim(a, pick); // bs.cpp:261
+  api->copy_prob(S2, a, MVX_ON);                   // NodeData(a), util.cpp:33-34
+  api->copy_prob(S3, a, MVX_ON);
+  if (quirks) {
+    api->set_col_bnds(S2, pick, MVX_UP, 0, std::floor(bound)); // bs.cpp:274
+    api->set_col_bnds(S3, pick, MVX_LO, std::ceil(bound), 0);  // bs.cpp:282
+  } else {
+    const int t = api->get_col_type(a, pick);
+    const double l = api->get_col_lb(a, pick), u = api->get_col_ub(a, pick);
+    if (t == MVX_LO || t == MVX_DB || t == MVX_FX)
+      api->set_col_bnds(S2, pick, (l == std::floor(bound)) ? MVX_FX : MVX_DB, l, std::floor(bound));
+    else
+      api->set_col_bnds(S2, pick, MVX_UP, 0, std::floor(bound));
+    if (t == MVX_UP || t == MVX_DB || t == MVX_FX)
+      api->set_col_bnds(S3, pick, (u == std::ceil(bound)) ? MVX_FX : MVX_DB, std::ceil(bound), u);
+    else
+      api->set_col_bnds(S3, pick, MVX_LO, std::ceil(bound), 0);
+  }
+  return 0;
+}
+
 int mvx_printInfo(const mvx_lp_api *api, const void *prob, int quirks, int *violated, int *nviolated) {
   auto r = printInfo(api ? api : &g_hip_api, prob, quirks != 0);
   *nviolated = (int)r.second.size();

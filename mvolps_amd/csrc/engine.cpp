@@ -761,7 +761,7 @@ struct BatchCtx {
   size_t stage_stride = 0;
 };
 static BatchCtx g_batch;
-static int g_batch_slots = 16;
+static int g_batch_slots = 64;
 
 static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
   if (!bc.stream) HIPCHECK(hipStreamCreateWithFlags(&bc.stream, hipStreamNonBlocking));
@@ -1216,6 +1216,7 @@ void tuning(int tr, int hot, int nt) {
 }
 
 void use_graphs(int on) { g_use_graphs = on != 0; }
+void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }
 void profile_enable(int on) { ctx().prof = on != 0; }
 void profile_reset() {
   Context &c = ctx();

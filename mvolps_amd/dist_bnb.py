@@ -23,7 +23,6 @@ Tree, oids, prune labels, events and the incumbent come out identical to the ser
 Best-bound order (util.cpp:170-186) picks by fresh child bounds and is not window-batchable; GMI
 cut rows are not carried by migration.  Both stay on the single-GPU driver.
 """
-import math
 from collections import deque
 
 import numpy as np
@@ -34,14 +33,6 @@ from . import capi
 NEG_INF = float("-inf")
 EV_PREGNANT, EV_INTEGER, EV_INFEASIBLE, EV_FATHOMED, EV_BRANCHED, EV_CANDIDATE = range(6)
 INTG, FEAS, BNDS, NONE = 0, 1, 3, 4
-
-
-def get_fract(x):
-    """util.cpp:11-23"""
-    f, _ = math.modf(x)
-    if f < 0.0:
-        f += 1
-    return f
 
 
 def branch_direction(oid):
@@ -73,8 +64,14 @@ class HipNodeEngine:
     def print_info(self, prob, quirks):
         return self._bnb.print_info(prob, quirks=quirks, table=self.table)
 
+    def classify(self, prob, root, quirks, var_strat):
+        return self._bnb.classify(prob, root, quirks, var_strat, table=self.table)
+
+    def make_children(self, a, pick, quirks):
+        return self._bnb.make_children(a, pick, quirks, table=self.table)
+
     def solve_many(self, probs):
-        """Independent handles solved concurrently (mvx_simplex_batch: one HIP stream each)."""
+        """Independent handles that share every launch (mvx_simplex_batch: one grid.z slot each)."""
         if not probs:
             return
         import ctypes as C
@@ -106,26 +103,6 @@ class _Node:
 
     def __init__(self, oid, owner, upper, inital=False):
         self.oid, self.owner, self.upper, self.inital = oid, owner, upper, inital
-
-
-def _pick_var(api, root, vars_, strat):
-    """ParameterObj::pickVar, util.cpp:190-230 (queries the never-solved ROOT problem)."""
-    if strat == 0:
-        return vars_[0]
-    if strat == 1:
-        cur_best = abs(get_fract(api.get_col_prim(root.h, vars_[0])) - 0.5)
-        index = vars_[0]
-        for i in vars_:
-            cur = abs(get_fract(api.get_col_prim(root.h, i)) - 0.5)
-            if cur < cur_best:
-                cur_best, index = cur, i
-        return index
-    best, index = 0.0, vars_[0]
-    for i in vars_:
-        cur = api.get_obj_coef(root.h, i)
-        if cur > best:
-            best, index = cur, i
-    return index
 
 
 def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limit=200000, per_rank=1, group=None):
@@ -181,13 +158,8 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
             mine.append((w, nd, a, a.it_cnt))
         engine.solve_many([a for (_, _, a, _) in mine])
         for w, nd, a, before in mine:
-            st, viol = engine.print_info(a, quirks)
-            acc = 0.0
-            for i in viol:
-                if i != 0:
-                    acc += get_fract(api.get_col_prim(a.h, i))
-            pick = _pick_var(api, root, viol, var_strat) if viol else 0
-            A[w] = torch.tensor([float(st), a.obj, float(len(viol)), acc, float(pick), float(a.it_cnt - before)], dtype=torch.float64)
+            st, obj, nviol, acc, pick = engine.classify(a, root, quirks, var_strat)
+            A[w] = torch.tensor([float(st), obj, float(nviol), acc, float(pick), float(a.it_cnt - before)], dtype=torch.float64)
             solved[nd.oid] = a
             if st == 1:
                 x_keep[nd.oid] = a.col_prim()
@@ -253,21 +225,7 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
             if nd.owner != rank:
                 continue
             a = solved[nd.oid]
-            bnd = api.get_col_prim(a.h, pick)  # bs.cpp:261
-            S2, S3 = a.copy(capi.ON), a.copy(capi.ON)
-            if quirks:
-                api.set_col_bnds(S2.h, pick, capi.UP, 0.0, math.floor(bnd))  # bs.cpp:274
-                api.set_col_bnds(S3.h, pick, capi.LO, math.ceil(bnd), 0.0)  # bs.cpp:282
-            else:
-                t, l, u = api.get_col_type(a.h, pick), api.get_col_lb(a.h, pick), api.get_col_ub(a.h, pick)
-                if t in (capi.LO, capi.DB, capi.FX):
-                    api.set_col_bnds(S2.h, pick, capi.FX if l == math.floor(bnd) else capi.DB, l, math.floor(bnd))
-                else:
-                    api.set_col_bnds(S2.h, pick, capi.UP, 0.0, math.floor(bnd))
-                if t in (capi.UP, capi.DB, capi.FX):
-                    api.set_col_bnds(S3.h, pick, capi.FX if u == math.ceil(bnd) else capi.DB, math.ceil(bnd), u)
-                else:
-                    api.set_col_bnds(S3.h, pick, capi.LO, math.ceil(bnd), 0.0)
+            S2, S3 = engine.make_children(a, pick, quirks)  # bs.cpp:261-282
             made.append((k, s2, s3, S2, S3, S2.it_cnt, S3.it_cnt))
         # every child of this round is an independent LP (bs.cpp:279,287): solve them together
         engine.solve_many([p for (_, _, _, S2, S3, _, _) in made for p in (S2, S3)])

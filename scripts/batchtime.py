@@ -30,8 +30,8 @@ for g in (1, 0):
     api.simplex_batch((C.c_void_p * 16)(*[k.h for k in kids]), 16, None, None)
     for ch in children(2):
         ch.simplex()
-for graphs, K in [(g, K) for g in (0,) for K in (1, 2, 4, 8, 16, 32, 64)]:
-    api.use_graphs(graphs)
+for graphs, K in [(g, K) for g in (16, 32, 64) for K in (16, 32, 64, 80)]:
+    api.set_batch_slots(graphs)
     K = min(K, len(frac))
     kids = children(K)
     api.sync()
@@ -47,5 +47,5 @@ for graphs, K in [(g, K) for g in (0,) for K in (1, 2, 4, 8, 16, 32, 64)]:
     api.simplex_batch(arr, K, None, None)
     t_b = time.perf_counter() - t
     assert all(a.obj == b_.obj for a, b_ in zip(kids, kids2))
-    print("graphs=%d K=%2d pivots=%5d  sequential %.2f ms (%.1f us/pivot)   batch %.2f ms (%.1f us/pivot)  speedup %.2fx" % (
+    print("slots=%d K=%2d pivots=%5d  sequential %.2f ms (%.1f us/pivot)   batch %.2f ms (%.1f us/pivot)  speedup %.2fx" % (
         graphs, K, piv, t_seq * 1e3, t_seq * 1e6 / piv, t_b * 1e3, t_b * 1e6 / piv, t_seq / t_b))

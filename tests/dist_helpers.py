@@ -27,6 +27,12 @@ class OracleNodeEngine:
     def print_info(self, prob, quirks):
         return self._bnb.print_info(prob, quirks=quirks, table=self.table)
 
+    def classify(self, prob, root, quirks, var_strat):
+        return self._bnb.classify(prob, root, quirks, var_strat, table=self.table)
+
+    def make_children(self, a, pick, quirks):
+        return self._bnb.make_children(a, pick, quirks, table=self.table)
+
     def solve_many(self, probs):
         for p in probs:
             p.simplex()
