@@ -47,11 +47,53 @@ def pmc_traffic(m, n):
     return best
 
 
-def cpu_baseline(m, n, seed, budget_s=12.0, max_pivots=400):
-    """Oracle (CPU restatement, OpenMP row-parallel update) on a bounded sample of the same LP."""
+def glpk_probe(A, b, c, budget_pivots=400):
+    """Opportunistic true-reference line (CPU-baseline plan 2): if a libglpk happens to be
+    installed on this host, time real glp_simplex on the same LP.  Never assumed; any failure -> absent."""
+    import ctypes as C
+    import ctypes.util
+
+    try:
+        name = ctypes.util.find_library("glpk")
+        if not name:
+            return {"glpk": "absent"}
+        g = C.CDLL(name)
+        g.glp_create_prob.restype = C.c_void_p
+        g.glp_get_obj_val.restype = C.c_double
+        g.glp_version.restype = C.c_char_p
+        m, n = A.shape
+        P = C.c_void_p(g.glp_create_prob())
+        g.glp_term_out(0)
+        g.glp_set_obj_dir(P, 2)
+        g.glp_add_rows(P, m)
+        g.glp_add_cols(P, n)
+        for j in range(n):
+            g.glp_set_col_bnds(P, j + 1, 2, C.c_double(0.0), C.c_double(0.0))
+            g.glp_set_obj_coef(P, j + 1, C.c_double(float(c[j])))
+        ind = (C.c_int * (n + 1))(*range(n + 1))
+        for i in range(m):
+            g.glp_set_row_bnds(P, i + 1, 3, C.c_double(0.0), C.c_double(float(b[i])))
+            val = (C.c_double * (n + 1))(0.0, *A[i].tolist())
+            g.glp_set_mat_row(P, i + 1, n, ind, val)
+        t0 = time.perf_counter()
+        g.glp_simplex(P, None)
+        el = time.perf_counter() - t0
+        it = getattr(g, "glp_get_it_cnt", None)
+        iters = int(it(P)) if it else None
+        out = {"glpk": g.glp_version().decode(), "seconds": el, "objective": float(g.glp_get_obj_val(P)), "iterations": iters}
+        g.glp_delete_prob(P)
+        return out
+    except Exception as e:  # pragma: no cover - depends on the host
+        return {"glpk": "probe failed: %s" % e}
+
+
+def cpu_baseline(m, n, seed, budget_s=9.0, max_pivots=400):
+    """Oracle (CPU restatement) on a bounded sample of the same LP: all host threads this job may use
+    (OpenMP row-parallel update) and, beside it, one thread."""
+    import ctypes as C
+
     threads = min(os.cpu_count() or 1, 16)
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    threads = int(os.environ["OMP_NUM_THREADS"])
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     from mvolps_amd import synth
     from oracle import oracle
 
@@ -59,22 +101,66 @@ def cpu_baseline(m, n, seed, budget_s=12.0, max_pivots=400):
     P = oracle.api().create()
     P.load_dense(A, b, c)
     P.simplex(it_lim=2)  # builds the tableau + touches the pages
-    piv0 = P.it_cnt
-    t0 = time.perf_counter()
-    while True:
-        P.simplex(it_lim=20)
-        el = time.perf_counter() - t0
-        if el >= budget_s or P.it_cnt - piv0 >= max_pivots or P.status == 5:
-            break
-    done = P.it_cnt - piv0
-    return {
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+
+    def run(nthreads, budget):
+        if gomp is not None:
+            gomp.omp_set_num_threads(nthreads)
+        piv0 = P.it_cnt
+        t0 = time.perf_counter()
+        while True:
+            P.simplex(it_lim=10)
+            el = time.perf_counter() - t0
+            if el >= budget or P.it_cnt - piv0 >= max_pivots or P.status == 5:
+                break
+        return (P.it_cnt - piv0), el
+
+    done, el = run(threads, budget_s)
+    done1, el1 = run(1, budget_s * 0.6) if gomp is not None else (0, 1.0)
+    out = {
         "value": done / el,
         "unit": "pivots/s",
         "cores": threads,
         "kind": "port",
-        "sample": "first %d pivots of the same %dx%d LP (seed %d), oracle/mvolps_oracle.c, %d OpenMP threads"
+        "sample": "%d pivots of the same %dx%d LP (seed %d) right after its first 2, oracle/mvolps_oracle.c, %d OpenMP threads"
         % (done, m, n, seed, threads),
+        "single_thread": {"value": done1 / el1, "pivots": done1} if done1 else None,
     }
+    out["reference_glpk"] = glpk_probe(A, b, c) if m * n <= 2048 * 4096 else glpk_probe(A[:1024, :2048].copy(), b[:1024], c[:2048])
+    return out
+
+
+def secondary(api):
+    """Other BASELINE configs on the same GPU, reported beside the headline (not part of `value`)."""
+    from mvolps_amd import dist_bnb, synth
+    from tests import lpgen
+
+    out = {}
+    # config 2: dense LP 1024x2048 -- cache-resident, latency-bound (BASELINE.md: report, do not headline)
+    A, b, c = synth.dense_lp(1024, 2048, 12345)
+    P = api.create()
+    P.load_dense(A, b, c)
+    P.simplex(it_lim=50)
+    api.sync()
+    t0 = time.perf_counter()
+    P.simplex(it_lim=800)
+    api.sync()
+    el = time.perf_counter() - t0
+    out["dense_lp_1024x2048"] = {"pivots_per_s": 800 / el, "us_per_pivot": el / 800 * 1e6,
+                                 "frac_of_hbm_roofline": 800 / el * bytes_per_pivot(1024, 2048) / 1e9 / HBM_PEAK_GBS}
+    # configs 3/5 shape: ILP 512x1024, FIFO B&B through the window coordinator (64 node LPs share each launch)
+    A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3)
+    eng = dist_bnb.HipNodeEngine(0)
+    dist_bnb.branch_and_bound(eng, lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=64, per_rank=32)  # warm-up
+    t0 = time.perf_counter()
+    r = dist_bnb.branch_and_bound(eng, lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=1500, per_rank=32)
+    el = time.perf_counter() - t0
+    out["bnb_ilp_512x1024"] = {"nodes": r["count"], "nodes_per_s": r["count"] / el, "pivots": r["total_pivots"],
+                               "pivots_per_s": r["total_pivots"] / el, "window": 32}
+    return out
 
 
 def main():
@@ -86,6 +172,7 @@ def main():
     ap.add_argument("--cols", type=int, default=8192, help="columns n of the dense LP")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements of configs 2 and 3/5")
     ap.add_argument("--profile-steps", type=int, default=100, help="extra pivots timed per-kernel with HIP events")
     args = ap.parse_args()
 
@@ -203,6 +290,11 @@ def main():
             "device_ms_per_step": device_ms / args.steps,
             "roofline": roof,
         }
+        if world == 1 and not args.no_secondary:
+            try:
+                out["secondary"] = secondary(api)
+            except Exception as e:  # the headline line must not depend on the side measurements
+                out["secondary"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(m, n, args.seed)
         print(json.dumps(out), flush=True)
