@@ -69,6 +69,10 @@ typedef struct {
                            integrality test has a 1e-9 tolerance */
   int lazy_pool;        /* 1 (default): generate only the cut cut.cpp:20 will actually add (the last
                            eligible column's); 0: generate and pool every cut like bs.cpp:250-255 */
+  int window;           /* FIFO order without cuts, engine with a batch entry: solve the front `window`
+                           nodes of the deque together and replay bs.cpp's decisions in queue order --
+                           same tree, oids, events and incumbent as node-at-a-time;
+                           default 32, 1 = node at a time */
 } mvx_bnb_params;
 
 /* B&B events at the emit points of bs.cpp (message.h EventType) */

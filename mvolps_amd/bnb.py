@@ -33,6 +33,7 @@ class BnbParams(C.Structure):
         ("max_nodes", C.c_int),
         ("reference_quirks", C.c_int),
         ("lazy_pool", C.c_int),
+        ("window", C.c_int),
     ]
 
 
@@ -132,13 +133,15 @@ def result_to_dict(res):
     }
 
 
-def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, lazy_pool=1, table=None):
+def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, lazy_pool=1, table=None, window=None):
     """Run the driver on `prob` (a capi.Prob).  table=None uses the gfx950 engine's own table."""
     L = lib()
     pr = BnbParams()
     L.mvx_bnb_default_params(C.byref(pr))
     pr.var_strat, pr.node_strat, pr.cut_strat, pr.max_nodes = var_strat, node_strat, cut_strat, max_nodes
     pr.reference_quirks, pr.lazy_pool = quirks, lazy_pool
+    if window is not None:
+        pr.window = window
     res = BnbResult()
     tptr = C.cast(C.pointer(table), C.c_void_p) if table is not None else None
     L.mvx_branchAndBound(tptr, prob.h, C.byref(pr), C.byref(res))

@@ -220,6 +220,7 @@ struct Recorder {
   std::vector<int> parent, prune;
   std::vector<double> bound;
   std::vector<mvx_bnb_event> events;
+  std::vector<mvx_bnb_event> *sink = nullptr; // window mode buffers events per node
   long long pivots = 0;
   void node(int oid, int pid) {
     if ((int)parent.size() <= oid) {
@@ -239,7 +240,7 @@ struct Recorder {
     e.sum_infeas = f7;
     e.n_violated = f8;
     e.pick = pick;
-    events.push_back(e);
+    (sink ? *sink : events).push_back(e);
   }
 };
 
@@ -255,6 +256,25 @@ T *dup(const std::vector<T> &v) {
   T *p = (T *)std::malloc(sizeof(T) * (v.empty() ? 1 : v.size()));
   if (!v.empty()) std::memcpy(p, v.data(), sizeof(T) * v.size());
   return p;
+}
+
+void pack_result(mvx_bnb_result *res, const Recorder &rec, int id, int count, int has_incumbent, double bestLower, int incumbent_oid,
+                 int n0, const std::vector<double> &xbest, int hit_limit) {
+  std::memset(res, 0, sizeof(*res));
+  res->n_nodes = id - 1;
+  res->parent = dup(rec.parent);
+  res->prune = dup(rec.prune);
+  res->node_bound = dup(rec.bound);
+  res->n_events = (int)rec.events.size();
+  res->events = dup(rec.events);
+  res->count = count;
+  res->has_incumbent = has_incumbent;
+  res->best_lower = bestLower;
+  res->incumbent_oid = incumbent_oid;
+  res->n = n0;
+  res->x = dup(xbest);
+  res->total_pivots = rec.pivots;
+  res->hit_limit = hit_limit;
 }
 
 int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm, mvx_bnb_result *res) { // bs.cpp:54
@@ -408,22 +428,170 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
   }
   leafContainer.clear();
   api->delete_prob(a);
+  pack_result(res, rec, id, count, has_incumbent, bestLower, incumbent_oid, n0, xbest, hit_limit);
+  return 0;
+}
 
-  std::memset(res, 0, sizeof(*res));
-  res->n_nodes = id - 1;
-  res->parent = dup(rec.parent);
-  res->prune = dup(rec.prune);
-  res->node_bound = dup(rec.bound);
-  res->n_events = (int)rec.events.size();
-  res->events = dup(rec.events);
-  res->count = count;
-  res->has_incumbent = has_incumbent;
-  res->best_lower = bestLower;
-  res->incumbent_oid = incumbent_oid;
-  res->n = n0;
-  res->x = dup(xbest);
-  res->total_pivots = rec.pivots;
-  res->hit_limit = hit_limit;
+// Window mode: the front W nodes of the FIFO deque are solved together (one batched launch carries
+// all of them), then bs.cpp's decisions are replayed in queue order.  With FIFO order children go to
+// the back (bs.cpp:297-298) and no node is discarded unsolved, so the next W nodes the serial loop
+// would pop are exactly the front W whatever their outcome: the tree, oids, events, pivot counts and
+// incumbent are those of the node-at-a-time loop above.
+int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm, mvx_bnb_result *res) {
+  MVOLP::ParameterObj params(api, prob, prm);
+  Recorder rec;
+  int id = 1;
+  const bool quirks = prm.reference_quirks != 0;
+  std::deque<std::shared_ptr<MVOLP::NodeData>> leafContainer;
+  auto S1 = std::make_shared<MVOLP::NodeData>(api, prob, id);
+  S1->inital = true;
+  rec.node(S1->oid, 0);
+  leafContainer.push_back(S1);
+  double bestLower = -std::numeric_limits<double>::infinity();
+  const int n0 = api->get_num_cols(prob);
+  std::vector<double> xbest((size_t)n0 + 1, 0.0);
+  int incumbent_oid = 0, has_incumbent = 0, hit_limit = 0, count = 0;
+  bool stop = false;
+
+  struct Branch {
+    size_t slot;
+    std::shared_ptr<MVOLP::NodeData> S2, S3;
+    int before2, before3;
+  };
+  while (!leafContainer.empty() && !stop) {
+    if (prm.max_nodes > 0 && count >= prm.max_nodes) {
+      hit_limit = 1;
+      break;
+    }
+    const size_t W = std::min(leafContainer.size(), (size_t)prm.window);
+    // A. clone + solve the window (bs.cpp:114-117)
+    std::vector<void *> a(W);
+    std::vector<int> before(W);
+    for (size_t w = 0; w < W; w++) {
+      a[w] = api->create_prob();
+      api->copy_prob(a[w], leafContainer[w]->prob, MVX_OFF);
+      before[w] = api->get_it_cnt(a[w]);
+    }
+    api->simplex_batch(a.data(), (int)W, nullptr, nullptr);
+    // B. replay in queue order
+    std::vector<std::vector<mvx_bnb_event>> node_events(W);
+    std::vector<Branch> branches;
+    size_t processed = 0;
+    for (size_t w = 0; w < W; w++) {
+      if (prm.max_nodes > 0 && count >= prm.max_nodes) {
+        hit_limit = 1;
+        stop = true;
+        break;
+      }
+      std::shared_ptr<MVOLP::NodeData> node = leafContainer[w];
+      void *aw = a[w];
+      rec.sink = &node_events[w];
+      rec.pivots += api->get_it_cnt(aw) - before[w];
+      processed++;
+      rec.emit(MVX_EV_PREGNANT, node->oid, api->get_obj_val(aw), 0.0, 0, 0);
+      auto ret = printInfo(api, aw, quirks);
+      const int status = ret.first;
+      const std::vector<int> &vars = ret.second;
+      if (node->inital) {
+        if (status == -1) {
+          rec.prune[(size_t)node->oid] = MVOLP::FEAS;
+          stop = true;
+          break;
+        }
+        if (status == 1) {
+          node->upperBound = api->get_obj_val(aw);
+          rec.bound[(size_t)node->oid] = node->upperBound;
+          rec.prune[(size_t)node->oid] = MVOLP::INTG;
+          stop = true;
+          break;
+        }
+      }
+      node->upperBound = api->get_obj_val(aw);
+      rec.bound[(size_t)node->oid] = node->upperBound;
+      if (status == 1) {
+        rec.prune[(size_t)node->oid] = MVOLP::INTG;
+        rec.emit(MVX_EV_INTEGER, node->oid, node->upperBound, 0.0, 0, 0);
+        if (node->upperBound > bestLower) {
+          bestLower = node->upperBound;
+          has_incumbent = 1;
+          incumbent_oid = node->oid;
+          for (int i = 1; i <= n0; i++) xbest[(size_t)i] = api->get_col_prim(aw, i);
+        }
+      } else if (status == -1) {
+        rec.prune[(size_t)node->oid] = MVOLP::FEAS;
+        rec.emit(MVX_EV_INFEASIBLE, node->oid, 0.0, 0.0, 0, 0);
+      } else if (api->get_obj_val(aw) <= bestLower) {
+        rec.prune[(size_t)node->oid] = MVOLP::BNDS;
+        rec.emit(MVX_EV_FATHOMED, node->oid, 0.0, 0.0, 0, 0);
+      } else {
+        double acc = 0;
+        for (int i : vars)
+          if (i != 0) acc += getFract(api->get_col_prim(aw, i));
+        const int pick = params.pickVar(vars);
+        rec.emit(MVX_EV_BRANCHED, node->oid, node->upperBound, acc, (int)vars.size(), pick);
+        Branch br;
+        br.slot = w;
+        br.S2 = std::make_shared<MVOLP::NodeData>(api, aw, id); // even oid (R), then odd (L): bs.cpp:43-52
+        br.S3 = std::make_shared<MVOLP::NodeData>(api, aw, id);
+        rec.node(br.S2->oid, node->oid);
+        rec.node(br.S3->oid, node->oid);
+        // same bounds as mvx_bnb_make_children, on the NodeData clones
+        const double bound = api->get_col_prim(aw, pick);
+        if (quirks) {
+          api->set_col_bnds(br.S2->prob, pick, MVX_UP, 0, std::floor(bound));
+          api->set_col_bnds(br.S3->prob, pick, MVX_LO, std::ceil(bound), 0);
+        } else {
+          const int t = api->get_col_type(aw, pick);
+          const double l = api->get_col_lb(aw, pick), u = api->get_col_ub(aw, pick);
+          if (t == MVX_LO || t == MVX_DB || t == MVX_FX)
+            api->set_col_bnds(br.S2->prob, pick, (l == std::floor(bound)) ? MVX_FX : MVX_DB, l, std::floor(bound));
+          else
+            api->set_col_bnds(br.S2->prob, pick, MVX_UP, 0, std::floor(bound));
+          if (t == MVX_UP || t == MVX_DB || t == MVX_FX)
+            api->set_col_bnds(br.S3->prob, pick, (u == std::ceil(bound)) ? MVX_FX : MVX_DB, std::ceil(bound), u);
+          else
+            api->set_col_bnds(br.S3->prob, pick, MVX_LO, std::ceil(bound), 0);
+        }
+        br.before2 = api->get_it_cnt(br.S2->prob);
+        br.before3 = api->get_it_cnt(br.S3->prob);
+        branches.push_back(br);
+        if (count > prm.loop_limit) { // bs.cpp:320-323
+          hit_limit = 1;
+          count++;
+          stop = true;
+          break;
+        }
+      }
+      count++;
+    }
+    // C. every child of this round is an independent LP (bs.cpp:279,287): one batched solve
+    std::vector<void *> kids;
+    for (auto &br : branches) {
+      kids.push_back(br.S2->prob);
+      kids.push_back(br.S3->prob);
+    }
+    if (!kids.empty()) api->simplex_batch(kids.data(), (int)kids.size(), nullptr, nullptr);
+    for (auto &br : branches) {
+      rec.pivots += (api->get_it_cnt(br.S2->prob) - br.before2) + (api->get_it_cnt(br.S3->prob) - br.before3);
+      br.S2->upperBound = api->get_obj_val(br.S2->prob);
+      br.S3->upperBound = api->get_obj_val(br.S3->prob);
+      rec.bound[(size_t)br.S2->oid] = br.S2->upperBound;
+      rec.bound[(size_t)br.S3->oid] = br.S3->upperBound;
+      leafContainer.push_back(br.S2);
+      leafContainer.push_back(br.S3);
+      rec.sink = &node_events[br.slot];
+      rec.emit(MVX_EV_CANDIDATE, br.S2->oid, br.S2->upperBound, 0.0, 0, 0);
+      rec.emit(MVX_EV_CANDIDATE, br.S3->oid, br.S3->upperBound, 0.0, 0, 0);
+    }
+    rec.sink = nullptr;
+    for (size_t w = 0; w < W; w++) {
+      rec.events.insert(rec.events.end(), node_events[w].begin(), node_events[w].end());
+      api->delete_prob(a[w]);
+    }
+    leafContainer.erase(leafContainer.begin(), leafContainer.begin() + (long)processed);
+  }
+  leafContainer.clear();
+  pack_result(res, rec, id, count, has_incumbent, bestLower, incumbent_oid, n0, xbest, hit_limit);
   return 0;
 }
 
@@ -474,6 +642,7 @@ void mvx_bnb_default_params(mvx_bnb_params *p) {
   p->max_nodes = 0;
   p->reference_quirks = 1;
   p->lazy_pool = 1;
+  p->window = 32;
 }
 
 int mvx_branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params *params, mvx_bnb_result *res) {
@@ -482,7 +651,10 @@ int mvx_branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params *
     mvx_bnb_default_params(&dflt);
     params = &dflt;
   }
-  return branchAndBound(api ? api : &g_hip_api, prob, *params, res);
+  if (!api) api = &g_hip_api;
+  if (api->simplex_batch && params->node_strat == 0 && params->cut_strat == 0 && params->window > 1)
+    return branchAndBoundWindow(api, prob, *params, res);
+  return branchAndBound(api, prob, *params, res);
 }
 
 void mvx_bnb_free_result(mvx_bnb_result *res) {

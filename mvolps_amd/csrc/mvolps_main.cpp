@@ -110,6 +110,7 @@ int main(int argc, char **argv) {
     }
   }
   if (input.CMDOptionExists("--repaired")) params.reference_quirks = 0;
+  if (input.CMDOptionExists("--window")) params.window = std::atoi(input.getCMDOption("--window").c_str());
   if (input.CMDOptionExists("--max-nodes")) params.max_nodes = std::atoi(input.getCMDOption("--max-nodes").c_str());
   if (input.CMDOptionExists("--server"))
     std::fprintf(stderr, "--server: the ZeroMQ sink is not part of this build; use --events FILE for the same stream\n");

@@ -800,6 +800,14 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
   return ORC_EFAIL;
 }
 
+int orc_simplex_batch(orc_prob **probs, int count, const orc_smcp *parm, int *rcs) {
+  for (int i = 0; i < count; i++) {
+    int rc = orc_simplex(probs[i], parm);
+    if (rcs) rcs[i] = rc;
+  }
+  return 0;
+}
+
 /* -------------------------------------------------------------------- query */
 int orc_get_obj_dir(const orc_prob *P) { return P->dir; }
 int orc_get_num_rows(const orc_prob *P) { return P->m; }

@@ -11,13 +11,18 @@ api = mvolps_amd.api()
 A, b, c, U = synth.dense_ilp(m, n, 12345, 3)
 root = lpgen.load_ilp(api, A, b, c, U)
 bnb.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=20)  # warm-up
-t = time.perf_counter()
-ref = bnb.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes)
-dt = time.perf_counter() - t
-print(json.dumps({"driver": "serial C++", "nodes": ref["count"], "pivots": ref["total_pivots"], "ms": dt * 1e3,
-                  "nodes_per_s": ref["count"] / dt, "pivots_per_s": ref["total_pivots"] / dt}), flush=True)
+ref = None
+for window in (1, 8, 32, 64, 128):
+    t = time.perf_counter()
+    r = bnb.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes, window=window)
+    dt = time.perf_counter() - t
+    if ref is None:
+        ref = r
+    print(json.dumps({"driver": "mvx_branchAndBound (C++)", "window": window, "nodes": r["count"], "pivots": r["total_pivots"],
+                      "ms": dt * 1e3, "nodes_per_s": r["count"] / dt, "pivots_per_s": r["total_pivots"] / dt,
+                      "same_tree_as_window1": r["events"] == ref["events"] and r["prune"] == ref["prune"]}), flush=True)
 eng = dist_bnb.HipNodeEngine(0)
-for per_rank in (1, 4, 16, 32, 64):
+for per_rank in (32, 64):
     t = time.perf_counter()
     got = dist_bnb.branch_and_bound(eng, lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes, per_rank=per_rank)
     dt = time.perf_counter() - t

@@ -41,6 +41,20 @@ def test_driver_matches_oracle_restatement(orc, case, node_strat, quirks):
     assert got["count"] > 5
 
 
+@pytest.mark.parametrize("window", [1, 2, 7, 64])
+def test_window_mode_is_serial_equivalent(orc, window):
+    """mvx_bnb_params.window: the front W nodes solved together, decisions replayed in queue order."""
+    from oracle import oracle
+
+    A, b, c, U = synth.dense_ilp(10, 20, 4, 3)
+    tab = oracle_table(orc)
+    assert tab.simplex_batch  # the oracle library exports a (sequential) batch entry for this test
+    for quirks, mx in ((0, 0), (1, 500)):
+        ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=quirks, max_nodes=mx)
+        got = bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=quirks, max_nodes=mx, table=tab, window=window)
+        same_result(got, ref)
+
+
 @pytest.mark.parametrize("lazy", [0, 1])
 @pytest.mark.parametrize("var_strat", [0, 1, 2])
 def test_driver_with_gmi_cuts_and_var_strategies(orc, var_strat, lazy):
