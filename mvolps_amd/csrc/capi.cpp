@@ -97,6 +97,7 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   dst->ctype = src->ctype; dst->clb = src->clb; dst->cub = src->cub;
   dst->status = src->status; dst->it_cnt = src->it_cnt; dst->last_ms = 0.0;
   dst->hint_dual = src->hint_dual;
+  std::memcpy(dst->last_tol, src->last_tol, sizeof(dst->last_tol));
   dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
   dst->sol_fresh = src->sol_fresh; dst->beta = src->beta; dst->dj = src->dj;
   mvx::engine_copy(dst, src);

@@ -48,8 +48,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 // ------------------------------------------------------------------------------ context
 // One solve context = one HIP stream with its own control block, scratch and staging.  The main
-// context serves every single-handle call; mvx_simplex_batch runs independent node solves on a
-// pool of them concurrently (B&B children, bs.cpp:279,287, are independent LPs).
+// context serves every single-handle call; mvx_simplex_batch has its own (BatchCtx below).
 struct SolveCtx {
   hipStream_t stream = nullptr;
   Ctl *d_ctl = nullptr;
@@ -78,7 +77,6 @@ struct SolveCtx {
 struct Context {
   int dev = -1;
   SolveCtx main;
-  std::vector<SolveCtx *> pool;
   // slab recycling (B&B clones come and go at one size)
   std::multimap<size_t, void *> free_slabs;
   size_t cached_bytes = 0;
@@ -130,10 +128,11 @@ static Context &ctx() {
   return *c;
 }
 
+static void sync_batch_stream();
 void sync_stream() {
   if (!g_ctx) return;
   HIPCHECK(hipStreamSynchronize(g_ctx->main.stream));
-  for (SolveCtx *sc : g_ctx->pool) HIPCHECK(hipStreamSynchronize(sc->stream));
+  sync_batch_stream();
 }
 
 static size_t stage_size(int m_cap, int ld) {
@@ -716,6 +715,20 @@ static bool job_collect(Context &c, SolveJob &J) {
   return false;
 }
 
+// A handle whose last solve ended OPT / NOFEAS / UNBND and that has not been edited since (every
+// edit resets `status`) would go through zero pivots and come out unchanged: bs.cpp:116-117 re-solves
+// exactly such clones at every pop.  Answer from the state at hand instead of queueing launches.
+static bool already_solved(const mvx_prob *P, const mvx_smcp &parm) {
+  if (!P->valid || parm.it_lim == 0) return false;
+  if (P->status != MVX_OPT && P->status != MVX_NOFEAS && P->status != MVX_UNBND) return false;
+  return P->last_tol[0] == parm.tol_bnd && P->last_tol[1] == parm.tol_dj && P->last_tol[2] == parm.tol_piv;
+}
+static void remember_tolerances(mvx_prob *P, const mvx_smcp &parm) {
+  P->last_tol[0] = parm.tol_bnd;
+  P->last_tol[1] = parm.tol_dj;
+  P->last_tol[2] = parm.tol_piv;
+}
+
 static bool job_prepare(SolveJob &J, mvx_prob *P, const mvx_smcp *parm) {
   J.P = P;
   if (parm) J.parm = *parm;
@@ -725,7 +738,13 @@ static bool job_prepare(SolveJob &J, mvx_prob *P, const mvx_smcp *parm) {
     J.rc = MVX_EFAIL;
     return false;
   }
+  if (already_solved(P, J.parm)) {
+    P->last_ms = 0.0;
+    J.rc = 0;
+    return false;
+  }
   if (!P->valid) build_slack_tableau(P);
+  remember_tolerances(P, J.parm);
   return true;
 }
 
@@ -761,6 +780,9 @@ struct BatchCtx {
   size_t stage_stride = 0;
 };
 static BatchCtx g_batch;
+static void sync_batch_stream() {
+  if (g_batch.stream) HIPCHECK(hipStreamSynchronize(g_batch.stream));
+}
 static int g_batch_slots = 64;
 
 static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
@@ -850,7 +872,13 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
       if (rcs) rcs[i] = MVX_EFAIL;
       continue;
     }
+    if (already_solved(P, parm)) {
+      P->last_ms = 0.0;
+      if (rcs) rcs[i] = 0;
+      continue;
+    }
     if (!P->valid) build_slack_tableau(P);
+    remember_tolerances(P, parm);
     pending.push_back(i);
     m_cap = std::max(m_cap, P->m_cap);
     ld = std::max(ld, P->ld);
@@ -1211,7 +1239,6 @@ void tuning(int tr, int hot, int nt) {
   if (g_ctx) { // partial-buffer sizes depend on the row-block depth
     g_ctx->main.sc_m_cap = 0;
     g_ctx->main.sc_ld = 0;
-    for (SolveCtx *x : g_ctx->pool) x->sc_m_cap = x->sc_ld = 0;
   }
 }
 

@@ -95,6 +95,7 @@ struct mvx_prob {
   int status = MVX_UNDEF;
   int it_cnt = 0;
   double last_ms = 0.0;
+  double last_tol[3] = {0.0, 0.0, 0.0}; // tolerances of the solve that produced `status`
   bool hint_dual = false; // last edit made a basic variable infeasible: start in the dual simplex
   // host mirrors of the basis (always in sync while valid)
   std::vector<int> bvar, nvar, nflag; // [m+1], [n+1], [n+1]
