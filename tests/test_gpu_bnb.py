@@ -110,3 +110,20 @@ def test_five_thousand_node_tree_three_ways(gpu, orc):
     for k in ("n_nodes", "parent", "prune", "count", "events", "node_bound", "x", "total_pivots", "incumbent_oid", "best_lower"):
         assert win[k] == ref_j[k], k
     assert abs(ref["best_lower"] - 210.0) <= 1e-9 * 210  # HiGHS milp optimum (tests/golden: ilp_16x32_s5)
+
+
+def test_config5_instance_digest(gpu):
+    """BASELINE config 5 instance (tests/golden/config5.json, written by scripts/config5.py): the first 3000
+    nodes of the 512x1024 FIFO tree through the windowed driver reproduce the recorded event-stream digest
+    (recorded from the node-at-a-time driver, whose first nodes are checked against the oracle above)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import config5
+
+    fx = json.load(open(os.path.join(root, "tests", "golden", "config5.json")))
+    A, b, c, U = synth.dense_ilp(fx["m"], fx["n"], fx["seed"], int(fx["U"]))
+    r = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=0, max_nodes=3000, window=32)
+    assert r["count"] == fx["prefix_3000"]["nodes"] and r["total_pivots"] == fx["prefix_3000"]["pivots"]
+    assert config5.digest(r) == fx["prefix_3000"]["sha256"]
