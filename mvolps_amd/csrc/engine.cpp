@@ -505,6 +505,12 @@ struct SolveJob {
   Ctl snap;
 };
 
+// No limit asked for: a safety cap stands in (Dantzig pricing has no anti-cycling rule; a stalled
+// degenerate LP must end with EITLIM rather than spin on the device).  Same formula as the oracle.
+static int pivot_budget(const mvx_prob *P, const mvx_smcp &parm) {
+  return parm.it_lim >= 0 ? parm.it_lim : 200 * (P->m + P->n) + 100000;
+}
+
 static void stage_copy_async(SolveCtx &sc, const mvx_prob *P) {
   HIPCHECK(hipMemcpyAsync(sc.h_stage, sc.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, sc.stream));
 }
@@ -518,7 +524,7 @@ static void job_begin(Context &c, SolveJob &J) {
   h->tol_bnd = J.parm.tol_bnd;
   h->tol_dj = J.parm.tol_dj;
   h->tol_piv = J.parm.tol_piv;
-  h->budget = J.parm.it_lim;
+  h->budget = pivot_budget(P, J.parm);
   upload_ctl(sc);
   HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
@@ -823,7 +829,7 @@ static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &pa
   h->m = P->m; h->n = P->n; h->ld = P->ld; h->m_cap = P->m_cap;
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = parm.tol_bnd; h->tol_dj = parm.tol_dj; h->tol_piv = parm.tol_piv;
-  h->phase = PH_START; h->done = D_RUN; h->budget = parm.it_lim;
+  h->phase = PH_START; h->done = D_RUN; h->budget = pivot_budget(P, parm);
   h->fstate = F_OFF;
   HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], h, sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
 }
@@ -907,6 +913,8 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   }
   int depth = 8;
   while (active > 0) {
+    // (two half-batches on two streams were measured: no gain -- kernels of different streams do
+    // not overlap usefully here, the update is bandwidth-bound and the select is tiny)
     for (int d = 0; d < depth; d++) {
       launch_select(bc.d_ctl, bc.stream, K);
       launch_update(bc.d_ctl, m_max, n_max, bc.stream, K);

@@ -769,7 +769,10 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
     return ORC_EFAIL;
   }
   if (!P->valid) build_slack_tableau(P);
-  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, parm->it_lim};
+  /* no limit asked for: a safety cap stands in (Dantzig pricing has no anti-cycling rule; a stalled
+     degenerate LP must end with EITLIM rather than spin).  Same formula in the HIP engine. */
+  int budget = parm->it_lim >= 0 ? parm->it_lim : 200 * (P->m + P->n) + 100000;
+  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, budget};
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
   for (int round = 0; round < 64; round++) {
     int to_upper = 0, sdir = 0;
