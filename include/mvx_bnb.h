@@ -43,6 +43,7 @@ typedef struct mvx_lp_api {
   int (*get_col_stat)(const void *P, int j);
   int (*get_row_stat)(const void *P, int i);
   double (*get_row_ub)(const void *P, int i);
+  double (*get_row_lb)(const void *P, int i);
   double (*get_col_ub)(const void *P, int j);
   double (*get_col_lb)(const void *P, int j);
   int (*get_col_type)(const void *P, int j);
@@ -65,10 +66,14 @@ typedef struct {
   int loop_limit;       /* bs.cpp:320: 200000 branchings */
   int max_nodes;        /* stop after this many loop iterations (<= 0: none) */
   int reference_quirks; /* 1 (default): bug-compatible with bs.cpp / util.cpp;
-                           0: children keep the opposite bound (bs.cpp:274,282 drop it) and the
-                           integrality test has a 1e-9 tolerance */
+                           0: children keep the opposite bound (bs.cpp:274,282 drop it), the
+                           integrality test has a 1e-9 tolerance, cuts are the repaired GMI of
+                           mvx_generateCutGMI and are not carried from node to node */
   int lazy_pool;        /* 1 (default): generate only the cut cut.cpp:20 will actually add (the last
                            eligible column's); 0: generate and pool every cut like bs.cpp:250-255 */
+  int cut_select;       /* reference_quirks = 0 only (changes results, hence not the
+                           default path).  0: add the last generated cut (cut.cpp:20); 1: add the
+                           ceil(cut_chance * k) most effective of the node's k cuts (-cf honoured) */
   int window;           /* FIFO order without cuts, engine with a batch entry: solve the front `window`
                            nodes of the deque together and replay bs.cpp's decisions in queue order --
                            same tree, oids, events and incumbent as node-at-a-time;
@@ -118,6 +123,11 @@ double mvx_getFract(double x); /* util.cpp:11-23 */
 int mvx_printInfo(const mvx_lp_api *api, const void *prob, int quirks, int *violated, int *nviolated);
 /* CutContainer generateCut3(glp_prob*, int j)  gmi.h:7; inds/vals hold n+1 entries, returns -1 when rejected */
 int mvx_generateCut3(const mvx_lp_api *api, const void *prob, int j, int *inds, double *vals, double *lb);
+
+/* Repaired Gomory mixed-integer cut (used when reference_quirks = 0): non-basic variables measured
+   from the bound they sit at, f0 from the row's own value, back-substitution by column index.
+   Same output layout as mvx_generateCut3; *efficacy = violation / 2-norm at the current vertex */
+int mvx_generateCutGMI(const mvx_lp_api *api, const void *prob, int j, int *inds, double *vals, double *lb, double *efficacy);
 
 /* ---- node-level helpers for window drivers (mvolps_amd/dist_bnb.py): one call per node instead of
    one per query.  Same arithmetic, same order as the loop body of bs.cpp. ---- */

@@ -11,7 +11,7 @@ from . import capi
 _FIELDS = [
     "create_prob", "erase_prob", "delete_prob", "copy_prob", "add_rows", "set_mat_row", "set_row_bnds", "set_col_bnds",
     "simplex", "get_status", "get_obj_val", "get_obj_coef", "get_col_prim", "get_num_rows", "get_num_cols", "get_col_kind",
-    "get_col_stat", "get_row_stat", "get_row_ub", "get_col_ub", "get_col_lb", "get_col_type", "get_mat_row", "eval_tab_row",
+    "get_col_stat", "get_row_stat", "get_row_ub", "get_row_lb", "get_col_ub", "get_col_lb", "get_col_type", "get_mat_row", "eval_tab_row",
     "get_it_cnt",
 ]
 _OPTIONAL = ["simplex_batch"]
@@ -33,6 +33,7 @@ class BnbParams(C.Structure):
         ("max_nodes", C.c_int),
         ("reference_quirks", C.c_int),
         ("lazy_pool", C.c_int),
+        ("cut_select", C.c_int),
         ("window", C.c_int),
     ]
 
@@ -133,13 +134,15 @@ def result_to_dict(res):
     }
 
 
-def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, lazy_pool=1, table=None, window=None):
+def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, lazy_pool=1, table=None, window=None,
+                     cut_select=0, cut_chance=1.0):
     """Run the driver on `prob` (a capi.Prob).  table=None uses the gfx950 engine's own table."""
     L = lib()
     pr = BnbParams()
     L.mvx_bnb_default_params(C.byref(pr))
     pr.var_strat, pr.node_strat, pr.cut_strat, pr.max_nodes = var_strat, node_strat, cut_strat, max_nodes
     pr.reference_quirks, pr.lazy_pool = quirks, lazy_pool
+    pr.cut_select, pr.cut_chance = cut_select, cut_chance
     if window is not None:
         pr.window = window
     res = BnbResult()

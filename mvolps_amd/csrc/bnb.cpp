@@ -136,6 +136,80 @@ CutContainer generateCut3(const mvx_lp_api *api, const void *in, int j) {
   return result;
 }
 
+// Repaired GMI -- see the derivation next to orc_generateCutGMI.
+CutContainer generateCutGMI(const mvx_lp_api *api, const void *in, int j, double *efficacy) {
+  CutContainer result;
+  result.oid = -1;
+  const int m = api->get_num_rows(in), n = api->get_num_cols(in);
+  if (api->get_col_kind(in, j) == MVX_CV) return result;
+  if (api->get_col_stat(in, j) != MVX_BS) return result;
+  const double beta = api->get_col_prim(in, j);
+  const double f0 = getFract(beta);
+  if (f0 < 1e-6 || f0 > 1.0 - 1e-6) return result;
+  std::vector<double> val2((size_t)n + 1, 0.0), work((size_t)m + n + 1, 0.0);
+  std::vector<int> ind2((size_t)n + 1, 0);
+  const int len = api->eval_tab_row(in, m + j, ind2.data(), val2.data());
+  double rhs = 1.0;
+  for (int t = 1; t <= len; t++) {
+    const int k = ind2[t];
+    const double alpha = val2[t];
+    int stat;
+    bool isint;
+    double lo, up;
+    if (k <= m) {
+      stat = api->get_row_stat(in, k);
+      isint = false;
+      lo = api->get_row_lb(in, k);
+      up = api->get_row_ub(in, k);
+    } else {
+      stat = api->get_col_stat(in, k - m);
+      isint = api->get_col_kind(in, k - m) != MVX_CV;
+      lo = api->get_col_lb(in, k - m);
+      up = api->get_col_ub(in, k - m);
+    }
+    if (stat == MVX_NS) continue;      // fixed: y_j = 0
+    if (stat == MVX_NF) return result; // free non-basic with a non-zero entry: no valid cut
+    const double abar = (stat == MVX_NL) ? -alpha : alpha;
+    double g;
+    if (isint) {
+      const double fj = getFract(abar);
+      g = (fj <= f0) ? fj / f0 : (1.0 - fj) / (1.0 - f0);
+    } else {
+      g = (abar >= 0.0) ? abar / f0 : -abar / (1.0 - f0);
+    }
+    if (stat == MVX_NL) {
+      work[k] += g;
+      rhs += g * lo;
+    } else {
+      work[k] -= g;
+      rhs -= g * up;
+    }
+  }
+  std::vector<double> rv((size_t)n + 1);
+  std::vector<int> ri((size_t)n + 1);
+  for (int i = 1; i <= m; i++) {
+    if (work[i] == 0.0) continue;
+    const int len2 = api->get_mat_row(in, i, ri.data(), rv.data());
+    for (int t = 1; t <= len2; t++) work[m + ri[t]] += work[i] * rv[t];
+  }
+  result.inds.resize((size_t)n + 1);
+  result.vals.resize((size_t)n + 1);
+  result.inds[0] = 0;
+  result.vals[0] = rhs;
+  double dot = 0.0, nrm = 0.0;
+  for (int k = 1; k <= n; k++) {
+    result.inds[k] = k;
+    result.vals[k] = work[m + k];
+    dot += result.vals[k] * api->get_col_prim(in, k);
+    nrm += result.vals[k] * result.vals[k];
+  }
+  result.lb = rhs;
+  if (!(nrm > 0.0)) return result;
+  *efficacy = (rhs - dot) / std::sqrt(nrm);
+  result.oid = 0;
+  return result;
+}
+
 namespace MVOLP {
 enum PruneType { INTG = 0, FEAS = 1, BNDS = 3, NONE = 4 }; // util.h:27
 
@@ -352,7 +426,7 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
         if (i != 0) acc += getFract(api->get_col_prim(a, i)); // bs.cpp:229-233
       leafContainer.erase(leafContainer.begin() + index);       // bs.cpp:247
 
-      if (params.IsCutEnabled()) { // bs.cpp:249-258
+      if (params.IsCutEnabled() && quirks) { // bs.cpp:249-258
         const int na = api->get_num_cols(a);
         if (prm.lazy_pool) {
           // only the pool's LAST cut is ever added (cut.cpp:20): generate just that one
@@ -369,6 +443,39 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
           }
         }
         pool.addCutConstraint(a);
+      } else if (params.IsCutEnabled()) {
+        // repaired cuts (reference_quirks = 0): this node's own cuts, chosen by cut_select / -cf
+        const int na = api->get_num_cols(a);
+        std::vector<CutContainer> local;
+        std::vector<double> eff;
+        for (int j = 1; j <= na; j++) {
+          double e = 0.0;
+          CutContainer c = generateCutGMI(api, a, j, &e);
+          if (c.oid != -1) {
+            local.push_back(std::move(c));
+            eff.push_back(e);
+          }
+        }
+        if (!local.empty()) {
+          int take = 1;
+          if (prm.cut_select == 1) {
+            take = (int)std::ceil(prm.cut_chance * (double)local.size());
+            take = std::max(1, std::min(take, (int)local.size()));
+          }
+          std::vector<char> used(local.size(), 0);
+          for (int t = 0; t < take; t++) {
+            int best = -1;
+            if (prm.cut_select == 0) best = (int)local.size() - 1; // cut.cpp:20: the last one
+            else
+              for (int q = 0; q < (int)local.size(); q++)
+                if (!used[(size_t)q] && (best < 0 || eff[(size_t)q] > eff[(size_t)best])) best = q; // ties: first generated
+            used[(size_t)best] = 1;
+            const CutContainer &cc = local[(size_t)best];
+            const int index = api->add_rows(a, 1);
+            api->set_mat_row(a, index, (int)cc.inds.size() - 1, cc.inds.data(), cc.vals.data());
+            api->set_row_bnds(a, index, MVX_LO, cc.lb, 0);
+          }
+        }
       }
       const int pick = params.pickVar(vars);         // bs.cpp:260
       const double bound = api->get_col_prim(a, pick); // bs.cpp:261
@@ -616,6 +723,7 @@ const mvx_lp_api g_hip_api = {
     [](const void *P, int j) { return mvx_get_col_stat((const mvx_prob *)P, j); },
     [](const void *P, int i) { return mvx_get_row_stat((const mvx_prob *)P, i); },
     [](const void *P, int i) { return mvx_get_row_ub((const mvx_prob *)P, i); },
+    [](const void *P, int i) { return mvx_get_row_lb((const mvx_prob *)P, i); },
     [](const void *P, int j) { return mvx_get_col_ub((const mvx_prob *)P, j); },
     [](const void *P, int j) { return mvx_get_col_lb((const mvx_prob *)P, j); },
     [](const void *P, int j) { return mvx_get_col_type((const mvx_prob *)P, j); },
@@ -642,6 +750,7 @@ void mvx_bnb_default_params(mvx_bnb_params *p) {
   p->max_nodes = 0;
   p->reference_quirks = 1;
   p->lazy_pool = 1;
+  p->cut_select = 0;
   p->window = 32;
 }
 
@@ -667,6 +776,17 @@ void mvx_bnb_free_result(mvx_bnb_result *res) {
 }
 
 double mvx_getFract(double x) { return getFract(x); }
+
+int mvx_generateCutGMI(const mvx_lp_api *api, const void *prob, int j, int *inds, double *vals, double *lb, double *efficacy) {
+  double e = 0.0;
+  CutContainer c = generateCutGMI(api ? api : &g_hip_api, prob, j, &e);
+  if (c.oid == -1) return -1;
+  std::memcpy(inds, c.inds.data(), c.inds.size() * sizeof(int));
+  std::memcpy(vals, c.vals.data(), c.vals.size() * sizeof(double));
+  *lb = c.lb;
+  *efficacy = e;
+  return 0;
+}
 
 int mvx_bnb_classify(const mvx_lp_api *api, const void *prob, const void *root, int quirks, int var_strat, double *out) {
   if (!api) api = &g_hip_api;

@@ -52,7 +52,8 @@ int main(int argc, char **argv) {
               << "    1. generate Gomory mixed integer\n"
               << "    -cf [0...1]\n"
               << "      Percentage of generated cuts to be added per node\n"
-              << "  --repaired      children keep the opposite bound, integrality within 1e-9\n"
+              << "  --repaired      children keep the opposite bound, integrality within 1e-9, repaired GMI cuts\n"
+              << "  --cut-select K  with --repaired -cm 1: 0 add the last cut, 1 add the -cf fraction of most effective cuts\n"
               << "  --max-nodes N   stop after N loop iterations\n"
               << "Help:\n  -h/--help\n";
     return 0;
@@ -110,6 +111,7 @@ int main(int argc, char **argv) {
     }
   }
   if (input.CMDOptionExists("--repaired")) params.reference_quirks = 0;
+  if (input.CMDOptionExists("--cut-select")) params.cut_select = std::atoi(input.getCMDOption("--cut-select").c_str());
   if (input.CMDOptionExists("--window")) params.window = std::atoi(input.getCMDOption("--window").c_str());
   if (input.CMDOptionExists("--max-nodes")) params.max_nodes = std::atoi(input.getCMDOption("--max-nodes").c_str());
   if (input.CMDOptionExists("--server"))

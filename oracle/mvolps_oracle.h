@@ -149,6 +149,11 @@ int orc_printInfo_ex(const orc_prob *P, int quirks, int *violated, int *nviolate
 /* generateCut3 (gmi.cpp:11-117).  inds/vals have n+1 entries (element 0: ind 0, val rhs).
    Returns -1 when rejected (non-integer or non-basic column), 0 on success. */
 int orc_generateCut3(const orc_prob *P, int j, int *inds, double *vals, double *lb);
+/* Repaired Gomory mixed-integer cut for basic integer column j (reference_quirks = 0): non-basic
+   variables measured from the bound they sit at, f0 from the row's own value, back-substitution by
+   column index.  Same output layout as orc_generateCut3; also returns the cut's efficacy
+   (violation / 2-norm) at the current vertex.  -1 when no cut can be derived. */
+int orc_generateCutGMI(const orc_prob *P, int j, int *inds, double *vals, double *lb, double *efficacy);
 
 typedef struct {
   int var_strat;  /* 0 VO, 1 VFP, 2 VGO   (util.h:30) */
@@ -158,8 +163,11 @@ typedef struct {
   int loop_limit; /* bs.cpp:320: 200000 */
   int max_nodes;  /* safety cap for tests: stop after this many loop iterations (<=0: none) */
   int reference_quirks; /* 1 (default): bug-compatible with bs.cpp/util.cpp;
-                           0: child bounds keep the opposite bound (bs.cpp:274,282 drop it) and
-                           printInfo uses the repaired integrality rule */
+                           0: child bounds keep the opposite bound (bs.cpp:274,282 drop it),
+                           printInfo uses the repaired integrality rule, cuts use orc_generateCutGMI
+                           and are not carried from node to node */
+  int cut_select;       /* reference_quirks = 0 only.  0: add the last generated cut (cut.cpp:20);
+                           1: add the ceil(cut_chance * k) most effective of the node's k cuts */
 } orc_bnb_params;
 
 /* event types follow message.h EventType order used at the bs.cpp emit points */

@@ -118,6 +118,81 @@ int orc_generateCut3(const orc_prob *P, int j, int *inds, double *vals, double *
   return 0;
 }
 
+/* Repaired GMI (not the reference's formula).  Tableau row of the basic
+   column: x_B = sum_j alpha_j x_Nj.  With y_j = x_j - l_j (at lower) or u_j - x_j (at upper) >= 0:
+   x_B + sum_j abar_j y_j = beta, abar_j = -alpha_j (lower) / +alpha_j (upper).  f0 = frac(beta);
+   integer y_j: g_j = f_j/f0 if f_j <= f0 else (1-f_j)/(1-f0), f_j = frac(abar_j);
+   continuous:  g_j = abar_j/f0 if abar_j >= 0 else -abar_j/(1-f0).   Cut: sum_j g_j y_j >= 1. */
+int orc_generateCutGMI(const orc_prob *P, int j, int *inds, double *vals, double *lb, double *efficacy) {
+  int m = orc_get_num_rows(P), n = orc_get_num_cols(P);
+  if (orc_get_col_kind(P, j) == ORC_CV) return -1;
+  if (orc_get_col_stat(P, j) != ORC_BS) return -1;
+  double beta = orc_get_col_prim(P, j);
+  double f0 = orc_getFract(beta);
+  if (f0 < 1e-6 || f0 > 1.0 - 1e-6) return -1;
+  double *val2 = (double *)xcalloc((size_t)n + 1, sizeof(double));
+  int *ind2 = (int *)xcalloc((size_t)n + 1, sizeof(int));
+  double *work = (double *)xcalloc((size_t)m + n + 1, sizeof(double)); /* coefficients on x (rows 1..m, cols m+1..) */
+  int len = orc_eval_tab_row(P, m + j, ind2, val2);
+  double rhs = 1.0;
+  int ok = 1;
+  for (int t = 1; t <= len && ok; t++) {
+    int k = ind2[t];
+    double alpha = val2[t];
+    int stat, isint;
+    double lo, up;
+    if (k <= m) {
+      stat = orc_get_row_stat(P, k);
+      isint = 0;
+      lo = orc_get_row_lb(P, k);
+      up = orc_get_row_ub(P, k);
+    } else {
+      stat = orc_get_col_stat(P, k - m);
+      isint = orc_get_col_kind(P, k - m) != ORC_CV;
+      lo = orc_get_col_lb(P, k - m);
+      up = orc_get_col_ub(P, k - m);
+    }
+    if (stat == ORC_NS) continue;             /* fixed: y_j = 0 */
+    if (stat == ORC_NF) { ok = 0; break; }     /* free non-basic with a non-zero entry: no valid cut */
+    double abar = (stat == ORC_NL) ? -alpha : alpha;
+    double g;
+    if (isint) {
+      double fj = orc_getFract(abar);
+      g = (fj <= f0) ? fj / f0 : (1.0 - fj) / (1.0 - f0);
+    } else {
+      g = (abar >= 0.0) ? abar / f0 : -abar / (1.0 - f0);
+    }
+    /* g*y_j with y_j = x - lo  or  up - x */
+    if (stat == ORC_NL) { work[k] += g; rhs += g * lo; }
+    else { work[k] -= g; rhs -= g * up; }
+  }
+  if (ok) {
+    /* auxiliary variables are row activities: x_i = sum_k A_ik x_(m+k) */
+    double *rv = (double *)xcalloc((size_t)n + 1, sizeof(double));
+    int *ri = (int *)xcalloc((size_t)n + 1, sizeof(int));
+    for (int i = 1; i <= m; i++) {
+      if (work[i] == 0.0) continue;
+      int len2 = orc_get_mat_row(P, i, ri, rv);
+      for (int t = 1; t <= len2; t++) work[m + ri[t]] += work[i] * rv[t];
+    }
+    free(rv); free(ri);
+    double dot = 0.0, nrm = 0.0;
+    inds[0] = 0;
+    vals[0] = rhs;
+    for (int k = 1; k <= n; k++) {
+      inds[k] = k;
+      vals[k] = work[m + k];
+      dot += vals[k] * orc_get_col_prim(P, k);
+      nrm += vals[k] * vals[k];
+    }
+    *lb = rhs;
+    *efficacy = (nrm > 0.0) ? (rhs - dot) / sqrt(nrm) : 0.0;
+    if (!(nrm > 0.0)) ok = 0;
+  }
+  free(val2); free(ind2); free(work);
+  return ok ? 0 : -1;
+}
+
 /* ----------------------------------------------------------------- cut pool */
 typedef struct {
   int *inds;
@@ -266,6 +341,7 @@ void orc_bnb_default_params(orc_bnb_params *p) {
   p->loop_limit = 200000; /* bs.cpp:320 */
   p->max_nodes = 0;
   p->reference_quirks = 1;
+  p->cut_select = 0;
 }
 
 static int solve(ctx_t *cx, orc_prob *p) {
@@ -350,7 +426,7 @@ int orc_branchAndBound(orc_prob *prob, const orc_bnb_params *params, orc_bnb_res
       for (int k = 0; k < nv; k++)
         if (vars[k] != 0) acc += orc_getFract(orc_get_col_prim(a, vars[k])); /* bs.cpp:229-233 */
 
-      if (params->cut_strat != 0) { /* bs.cpp:249-258 */
+      if (params->cut_strat != 0 && params->reference_quirks) { /* bs.cpp:249-258 */
         int na = orc_get_num_cols(a);
         for (int j = 1; j <= na; j++) {
           cut_t c;
@@ -365,6 +441,50 @@ int orc_branchAndBound(orc_prob *prob, const orc_bnb_params *params, orc_bnb_res
           }
         }
         pool_add_cut_constraint(&pool, a);
+      } else if (params->cut_strat != 0) {
+        /* repaired cuts: this node's own cuts only, chosen by cut_select / cut_chance */
+        int na = orc_get_num_cols(a);
+        pool_t local;
+        memset(&local, 0, sizeof(local));
+        double *eff = (double *)xcalloc((size_t)na + 1, sizeof(double));
+        for (int j = 1; j <= na; j++) {
+          cut_t c;
+          c.len = na + 1;
+          c.inds = (int *)xcalloc((size_t)na + 1, sizeof(int));
+          c.vals = (double *)xcalloc((size_t)na + 1, sizeof(double));
+          double e = 0.0;
+          if (orc_generateCutGMI(a, j, c.inds, c.vals, &c.lb, &e) != -1) {
+            eff[local.n] = e;
+            pool_add(&local, c);
+          } else {
+            free(c.inds);
+            free(c.vals);
+          }
+        }
+        if (local.n > 0) {
+          int take = 1;
+          if (params->cut_select == 1) {
+            take = (int)ceil(params->cut_chance * local.n);
+            if (take < 1) take = 1;
+            if (take > local.n) take = local.n;
+          }
+          char *used = (char *)xcalloc((size_t)local.n, 1);
+          for (int t = 0; t < take; t++) {
+            int best = -1;
+            if (params->cut_select == 0) best = local.n - 1; /* cut.cpp:20: the last one */
+            else
+              for (int q = 0; q < local.n; q++)
+                if (!used[q] && (best < 0 || eff[q] > eff[best])) best = q; /* ties: first generated */
+            used[best] = 1;
+            cut_t *cc = &local.cuts[best];
+            int index = orc_add_rows(a, 1);
+            orc_set_mat_row(a, index, cc->len - 1, cc->inds, cc->vals);
+            orc_set_row_bnds(a, index, ORC_LO, cc->lb, 0);
+          }
+          free(used);
+        }
+        free(eff);
+        pool_free(&local);
       }
       int pick = pick_var(params, prob, vars, nv);  /* bs.cpp:260 */
       double bound = orc_get_col_prim(a, pick);      /* bs.cpp:261 */

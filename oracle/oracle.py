@@ -21,6 +21,7 @@ class BnbParams(C.Structure):
         ("loop_limit", C.c_int),
         ("max_nodes", C.c_int),
         ("reference_quirks", C.c_int),
+        ("cut_select", C.c_int),
     ]
 
 
@@ -77,6 +78,7 @@ def api():
             "printInfo": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "printInfo_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "generateCut3": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+            "generateCutGMI": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
             "pack_size": (C.c_longlong, [C.c_void_p]),
             "pack": (C.c_int, [C.c_void_p, C.c_void_p]),
             "unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -111,12 +113,13 @@ def result_to_dict(res):
     return out
 
 
-def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1):
+def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, cut_select=0, cut_chance=1.0):
     a = api()
     pr = BnbParams()
     a.bnb_default_params(C.byref(pr))
     pr.var_strat, pr.node_strat, pr.cut_strat, pr.max_nodes = var_strat, node_strat, cut_strat, max_nodes
     pr.reference_quirks = quirks
+    pr.cut_select, pr.cut_chance = cut_select, cut_chance
     res = BnbResult()
     a.branchAndBound(prob.h, C.byref(pr), C.byref(res))
     out = result_to_dict(res)

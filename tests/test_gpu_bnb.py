@@ -127,3 +127,18 @@ def test_config5_instance_digest(gpu):
     r = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=0, max_nodes=3000, window=32)
     assert r["count"] == fx["prefix_3000"]["nodes"] and r["total_pivots"] == fx["prefix_3000"]["pivots"]
     assert config5.digest(r) == fx["prefix_3000"]["sha256"]
+
+
+def test_repaired_gmi_cuts_on_gpu(gpu, orc):
+    """Non-default cut path (reference_quirks = 0): repaired GMI + efficacy selection with -cf, GPU vs oracle
+    bit-exact, optimum equal to the HiGHS milp golden."""
+    from oracle import oracle
+
+    case = GOLD["ilp"][4]  # ilp_10x20_s4
+    A, b, c, U = synth.dense_ilp(case["m"], case["n"], case["seed"], int(case["U"]))
+    for kw in (dict(cut_select=0), dict(cut_select=1, cut_chance=0.4)):
+        kw.update(node_strat=1, quirks=0, cut_strat=1)
+        ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), **kw)
+        got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), **kw)
+        same_result(got, ref)
+        assert abs(got["best_lower"] - case["ilp_obj"]) <= 1e-9 * abs(case["ilp_obj"])
