@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements of configs 2 and 3/5")
-    ap.add_argument("--profile-steps", type=int, default=100, help="extra pivots timed per-kernel with HIP events")
+    ap.add_argument("--profile-steps", type=int, default=200, help="extra pivots timed per-kernel with HIP events")
     args = ap.parse_args()
 
     import torch
@@ -235,7 +235,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el_max = float(t.item())
 
-    # per-kernel pass: HIP events around every k_fb launch, on the engine's own stream
+    # per-kernel pass: HIP events around every k_fb launch, on the engine's own stream.  It runs on the
+    # same handle right after the timed region (the next pivots of the same LP) rather than inside it:
+    # two event records per pivot cost ~6 us/pivot (scripts/evcost.py), which would distort `value`.
     roof = None
     if rank == 0:
         api.profile_reset()
