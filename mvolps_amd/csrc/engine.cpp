@@ -512,6 +512,7 @@ static int pivot_budget(const mvx_prob *P, const mvx_smcp &parm) {
 }
 
 static void stage_copy_async(SolveCtx &sc, const mvx_prob *P) {
+  HIPCHECK(hipEventRecord(sc.ev_b, sc.stream)); // end of the device work queued so far (last_solve_ms)
   HIPCHECK(hipMemcpyAsync(sc.h_stage, sc.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, sc.stream));
 }
 
@@ -537,8 +538,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
   const int m = P->m, n = P->n;
   J.ev_used = 0;
   if (J.mode == SolveJob::FINAL) {
-    HIPCHECK(hipEventRecord(sc.ev_b, sc.stream));
-    launch_export(sc.d_ctl, sc.d_stage, m, n, 1, sc.stream); // forced: phase-1 exits and FAIL paths included
+    launch_export(sc.d_ctl, sc.d_stage, m, n, 1, sc.stream); // forced export (state left by a host-side decision)
     stage_copy_async(sc, P);
     return;
   }
@@ -630,43 +630,50 @@ static void job_enqueue(Context &c, SolveJob &J) {
   HIPCHECK(hipGraphLaunch(it->second, sc.stream));
 }
 
+// The staging buffer holds the control block and, because the solve has ended (k_export packs the
+// mirrors whenever done != RUN), the basis / solution mirrors: publish them on the handle.
+static bool job_finalize(SolveJob &J) {
+  mvx_prob *P = J.P;
+  SolveCtx &sc = *J.sc;
+  const Ctl &snap = J.snap;
+  const unsigned char *s = sc.h_stage;
+  const double *beta = (const double *)(s + sizeof(Ctl));
+  const double *dj = beta + (P->m_cap + 1);
+  const int *bv = (const int *)(dj + P->ld);
+  const int *nv = bv + (P->m_cap + 1);
+  const int *nf = nv + P->ld;
+  P->beta.assign(beta, beta + P->m + 1);
+  P->dj.assign(dj, dj + P->n + 1);
+  P->bvar.assign(bv, bv + P->m + 1);
+  P->nvar.assign(nv, nv + P->n + 1);
+  P->nflag.assign(nf, nf + P->n + 1);
+  rebuild_pos(P);
+  P->sol_fresh = true;
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, sc.ev_a, sc.ev_b));
+  P->last_ms = ms;
+  P->it_cnt += snap.it_cnt;
+  P->hint_dual = false;
+  switch (J.done) {
+    case D_OPT: P->status = MVX_OPT; J.rc = 0; break;
+    case D_UNBND: P->status = MVX_UNBND; J.rc = 0; break;
+    case D_NOFEAS: P->status = MVX_NOFEAS; J.rc = 0; break;
+    case D_ITLIM:
+      P->status = (snap.phase == PH_PRIMAL2) ? MVX_FEAS : MVX_INFEAS;
+      J.rc = MVX_EITLIM;
+      break;
+    default: P->status = MVX_UNDEF; J.rc = MVX_EFAIL; break;
+  }
+  return true;
+}
+
 // the job's stream has been synchronised; returns true when the solve is complete
 static bool job_collect(Context &c, SolveJob &J) {
   mvx_prob *P = J.P;
   SolveCtx &sc = *J.sc;
   Ctl &snap = J.snap;
   std::memcpy(&snap, sc.h_stage, sizeof(Ctl));
-  if (J.mode == SolveJob::FINAL) {
-    const unsigned char *s = sc.h_stage;
-    const double *beta = (const double *)(s + sizeof(Ctl));
-    const double *dj = beta + (P->m_cap + 1);
-    const int *bv = (const int *)(dj + P->ld);
-    const int *nv = bv + (P->m_cap + 1);
-    const int *nf = nv + P->ld;
-    P->beta.assign(beta, beta + P->m + 1);
-    P->dj.assign(dj, dj + P->n + 1);
-    P->bvar.assign(bv, bv + P->m + 1);
-    P->nvar.assign(nv, nv + P->n + 1);
-    P->nflag.assign(nf, nf + P->n + 1);
-    rebuild_pos(P);
-    P->sol_fresh = true;
-    float ms = 0.f;
-    HIPCHECK(hipEventElapsedTime(&ms, sc.ev_a, sc.ev_b));
-    P->last_ms = ms;
-    P->it_cnt += snap.it_cnt;
-    P->hint_dual = false;
-    switch (J.done) {
-      case D_OPT: P->status = MVX_OPT; J.rc = 0; break;
-      case D_UNBND: P->status = MVX_UNBND; J.rc = 0; break;
-      case D_NOFEAS: P->status = MVX_NOFEAS; J.rc = 0; break;
-      case D_ITLIM:
-        P->status = (snap.phase == PH_PRIMAL2) ? MVX_FEAS : MVX_INFEAS;
-        J.rc = MVX_EITLIM;
-        break;
-      default: P->status = MVX_UNDEF; J.rc = MVX_EFAIL; break;
-    }
-    return true;
-  }
+  if (J.mode == SolveJob::FINAL) return job_finalize(J);
   if (J.mode == SolveJob::PHASE1) {
     if (snap.done == D_RUN) {
       J.pb = std::min(J.pb * 2, 64);
@@ -689,8 +696,7 @@ static bool job_collect(Context &c, SolveJob &J) {
       return false;
     }
     J.done = snap.done;
-    J.mode = SolveJob::FINAL;
-    return false;
+    return job_finalize(J); // the same batch's export already packed the mirrors
   }
   if (J.profiled) {
     // once the solve finishes inside a batch the queued-ahead launches are no-ops; only the
@@ -713,10 +719,7 @@ static bool job_collect(Context &c, SolveJob &J) {
     J.pb = 4;
     return false;
   }
-  if (J.done != D_RUN) {
-    J.mode = SolveJob::FINAL;
-    return false;
-  }
+  if (J.done != D_RUN) return job_finalize(J); // the same batch's export already packed the mirrors
   J.batch = std::min(J.batch * 2, 256);
   return false;
 }

@@ -70,13 +70,35 @@ __device__ Cand block_best(Cand c, Cand *lds) {
   return lds[16];
 }
 
-__device__ Cand dev_infeas_row(const Ctl *c, Cand *lds) {
+// Kernel constants of one step: pointers, geometry and tolerances copied out of the control block
+// at kernel entry (one burst of scalar loads) instead of being re-fetched, dependently, inside
+// every helper.
+struct KC {
+  double *T;
+  const double *blb, *bub, *nlb, *nub;
+  int *nflag;
+  double *colq, *srow;
+  int m, n, ld;
+  double tol_bnd, tol_dj, tol_piv, sgn;
+};
+__device__ __forceinline__ KC load_kc(const Ctl *c) {
+  KC k;
+  k.T = c->T;
+  k.blb = c->blb; k.bub = c->bub; k.nlb = c->nlb; k.nub = c->nub;
+  k.nflag = c->nflag;
+  k.colq = c->colq; k.srow = c->srow;
+  k.m = c->m; k.n = c->n; k.ld = c->ld;
+  k.tol_bnd = c->tol_bnd; k.tol_dj = c->tol_dj; k.tol_piv = c->tol_piv; k.sgn = c->sgn;
+  return k;
+}
+
+__device__ Cand dev_infeas_row(const KC &k, Cand *lds) {
   Cand best{0.0, 0.0, 0, 0};
-  const size_t ld = (size_t)c->ld;
-  const double tol = c->tol_bnd;
-  for (int i = 1 + TIDX; i <= c->m; i += (int)blockDim.x) {
-    const double beta = c->T[(size_t)i * ld];
-    const double lb = c->blb[i], ub = c->bub[i];
+  const size_t ld = (size_t)k.ld;
+  const double tol = k.tol_bnd;
+  for (int i = 1 + TIDX; i <= k.m; i += (int)blockDim.x) {
+    const double beta = k.T[(size_t)i * ld];
+    const double lb = k.blb[i], ub = k.bub[i];
     double viol = 0.0;
     int up = 0;
     if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) viol = lb - beta;
@@ -92,11 +114,11 @@ __device__ Cand dev_infeas_row(const Ctl *c, Cand *lds) {
   return block_best<0>(best, lds);
 }
 
-__device__ Cand dev_price(const Ctl *c, const double *cost, double sgn, Cand *lds) {
+__device__ Cand dev_price(const KC &k, const double *cost, double sgn, Cand *lds) {
   Cand best{0.0, 0.0, 0, 0};
-  const double tol = c->tol_dj;
-  for (int j = 1 + TIDX; j <= c->n; j += (int)blockDim.x) {
-    const int f = c->nflag[j];
+  const double tol = k.tol_dj;
+  for (int j = 1 + TIDX; j <= k.n; j += (int)blockDim.x) {
+    const int f = k.nflag[j];
     if (f == MVX_NS) continue;
     const double dj = sgn * cost[j];
     const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
@@ -144,28 +166,28 @@ __device__ __forceinline__ bool ratio_row(double a, int sdir, double beta, doubl
 
 // Primal ratio test for entering column q moving in direction sdir; also copies the pivot
 // column into colq[0..m].  g (nullable) = phase-1 infeasibility signs.
-__device__ Cand dev_primal_ratio(const Ctl *c, int q, int sdir, const int *g, Cand *lds) {
+__device__ Cand dev_primal_ratio(const KC &k, int q, int sdir, const int *g, Cand *lds) {
   Cand best{0.0, 0.0, 0, 0};
-  const size_t ld = (size_t)c->ld;
-  const double tp = c->tol_piv;
-  for (int i = TIDX; i <= c->m; i += (int)blockDim.x) {
-    const double a = c->T[(size_t)i * ld + q];
-    c->colq[i] = a;
+  const size_t ld = (size_t)k.ld;
+  const double tp = k.tol_piv;
+  for (int i = TIDX; i <= k.m; i += (int)blockDim.x) {
+    const double a = k.T[(size_t)i * ld + q];
+    k.colq[i] = a;
     if (i == 0) continue;
     Cand x;
-    if (ratio_row(a, sdir, c->T[(size_t)i * ld], c->blb[i], c->bub[i], g ? g[i] : 0, tp, i, x) && cand_better<1>(x, best)) best = x;
+    if (ratio_row(a, sdir, k.T[(size_t)i * ld], k.blb[i], k.bub[i], g ? g[i] : 0, tp, i, x) && cand_better<1>(x, best)) best = x;
   }
   return block_best<1>(best, lds);
 }
 
-__device__ Cand dev_dual_ratio(const Ctl *c, int p, int to_upper, Cand *lds) {
+__device__ Cand dev_dual_ratio(const KC &k, int p, int to_upper, Cand *lds) {
   Cand best{0.0, 0.0, 0, 0};
-  const double *rowp = c->T + (size_t)p * c->ld;
-  const double *row0 = c->T;
-  const double tp = c->tol_piv, sgn = c->sgn;
+  const double *rowp = k.T + (size_t)p * k.ld;
+  const double *row0 = k.T;
+  const double tp = k.tol_piv, sgn = k.sgn;
   const bool need_inc = !to_upper;
-  for (int j = 1 + TIDX; j <= c->n; j += (int)blockDim.x) {
-    const int f = c->nflag[j];
+  for (int j = 1 + TIDX; j <= k.n; j += (int)blockDim.x) {
+    const int f = k.nflag[j];
     if (f == MVX_NS) continue;
     const double a = rowp[j];
     const double aa = need_inc ? a : -a;
@@ -194,13 +216,13 @@ __device__ __forceinline__ int dev_leave_flag(double lb, double ub, int to_upper
 }
 
 // Scale the pivot row into srow and publish the pivot description.  All threads call.
-__device__ void dev_prepare_pivot(Ctl *c, int p, int q, int p_up) {
-  const double *rowp = c->T + (size_t)p * c->ld;
+__device__ void dev_prepare_pivot(const KC &k, Ctl *c, int p, int q, int p_up) {
+  const double *rowp = k.T + (size_t)p * k.ld;
   const double piv = rowp[q];
-  const double bound = p_up ? c->bub[p] : c->blb[p];
-  for (int j = TIDX; j <= c->n; j += (int)blockDim.x) {
+  const double bound = p_up ? k.bub[p] : k.blb[p];
+  for (int j = TIDX; j <= k.n; j += (int)blockDim.x) {
     const double v = rowp[j];
-    c->srow[j] = (j == 0) ? (v - bound) / piv : v / piv;
+    k.srow[j] = (j == 0) ? (v - bound) / piv : v / piv;
   }
   if (TIDX == 0) {
     c->step = ST_PIVOT;
@@ -209,27 +231,27 @@ __device__ void dev_prepare_pivot(Ctl *c, int p, int q, int p_up) {
     c->p_up = p_up;
     c->piv = piv;
     c->bound = bound;
-    c->xq = dev_nb_value(c->nflag[q], c->nlb[q], c->nub[q]);
-    c->leave_flag = dev_leave_flag(c->blb[p], c->bub[p], p_up);
+    c->xq = dev_nb_value(k.nflag[q], k.nlb[q], k.nub[q]);
+    c->leave_flag = dev_leave_flag(k.blb[p], k.bub[p], p_up);
   }
 }
 
 // Entering column chosen: ratio test, then bound flip (done here) or pivot preparation.
 // Returns false when no row blocks (unbounded ray).
-__device__ bool dev_primal_step(Ctl *c, int q, int sdir, const int *g, Cand *lds) {
-  Cand r = dev_primal_ratio(c, q, sdir, g, lds);
-  const double lbq = c->nlb[q], ubq = c->nub[q];
-  const int fq = c->nflag[q];
+__device__ bool dev_primal_step(const KC &k, Ctl *c, int q, int sdir, const int *g, Cand *lds) {
+  Cand r = dev_primal_ratio(k, q, sdir, g, lds);
+  const double lbq = k.nlb[q], ubq = k.nub[q];
+  const int fq = k.nflag[q];
   if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
     const double tf = ubq - lbq;
     if (r.idx == 0 || tf <= r.k1) {
       const double delta = (sdir > 0) ? tf : -tf;
       __syncthreads(); // colq complete
-      const size_t ld = (size_t)c->ld;
-      for (int i = TIDX; i <= c->m; i += (int)blockDim.x)
-        c->T[(size_t)i * ld] = fma(c->colq[i], delta, c->T[(size_t)i * ld]);
+      const size_t ld = (size_t)k.ld;
+      for (int i = TIDX; i <= k.m; i += (int)blockDim.x)
+        k.T[(size_t)i * ld] = fma(k.colq[i], delta, k.T[(size_t)i * ld]);
       if (TIDX == 0) {
-        c->nflag[q] = (sdir > 0) ? MVX_NU : MVX_NL;
+        k.nflag[q] = (sdir > 0) ? MVX_NU : MVX_NL;
         c->step = ST_FLIP;
         c->n_flips++;
       }
@@ -237,7 +259,7 @@ __device__ bool dev_primal_step(Ctl *c, int q, int sdir, const int *g, Cand *lds
     }
   }
   if (r.idx == 0) return false;
-  dev_prepare_pivot(c, r.idx, q, r.aux);
+  dev_prepare_pivot(k, c, r.idx, q, r.aux);
   return true;
 }
 
@@ -255,16 +277,17 @@ __device__ __forceinline__ void dev_finish(Ctl *c, int code, int phase, int roun
 __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
   __shared__ Cand lds[17];
   c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
+  const KC k = load_kc(c); // every pointer / constant the step needs, fetched in one burst
   if (c->done != D_RUN) return;
   int phase = c->phase, rounds = c->rounds;
   int p = 0, p_up = 0, q = 0, sdir = 0, kind = 0; // kind 1 primal, 2 dual
   for (;;) {
     if (phase == PH_START) {
-      Cand r = dev_infeas_row(c, lds);
+      Cand r = dev_infeas_row(k, lds);
       if (r.idx == 0) {
         phase = PH_PRIMAL2;
       } else {
-        Cand pr = dev_price(c, c->T, c->sgn, lds);
+        Cand pr = dev_price(k, k.T, k.sgn, lds);
         if (pr.idx != 0) {
           dev_finish(c, D_NEED_PHASE1, PH_PHASE1, rounds);
           return;
@@ -277,14 +300,14 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
       }
     }
     if (phase == PH_PRIMAL2) {
-      Cand pr = dev_price(c, c->T, c->sgn, lds);
+      Cand pr = dev_price(k, k.T, k.sgn, lds);
       if (pr.idx != 0) {
         q = pr.idx;
         sdir = pr.aux;
         kind = 1;
         break;
       }
-      Cand r = dev_infeas_row(c, lds);
+      Cand r = dev_infeas_row(k, lds);
       if (r.idx == 0) {
         dev_finish(c, D_OPT, phase, rounds);
         return;
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
       break;
     }
     if (phase == PH_DUAL) {
-      Cand r = dev_infeas_row(c, lds);
+      Cand r = dev_infeas_row(k, lds);
       if (r.idx != 0) {
         p = r.idx;
         p_up = r.aux;
@@ -319,20 +342,20 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
     return;
   }
   if (kind == 1) {
-    if (!dev_primal_step(c, q, sdir, nullptr, lds)) {
+    if (!dev_primal_step(k, c, q, sdir, nullptr, lds)) {
       dev_finish(c, D_UNBND, phase, rounds);
       return;
     }
   } else {
-    Cand dr = dev_dual_ratio(c, p, p_up, lds);
+    Cand dr = dev_dual_ratio(k, p, p_up, lds);
     if (dr.idx == 0) {
       dev_finish(c, D_NOFEAS, phase, rounds);
       return;
     }
     q = dr.idx;
-    const size_t ld = (size_t)c->ld;
-    for (int i = TIDX; i <= c->m; i += (int)blockDim.x) c->colq[i] = c->T[(size_t)i * ld + q];
-    dev_prepare_pivot(c, p, q, p_up);
+    const size_t ld = (size_t)k.ld;
+    for (int i = TIDX; i <= k.m; i += (int)blockDim.x) k.colq[i] = k.T[(size_t)i * ld + q];
+    dev_prepare_pivot(k, c, p, q, p_up);
   }
   if (TIDX == 0) {
     c->phase = phase;
@@ -372,8 +395,9 @@ __global__ __launch_bounds__(1024) void k_p1_head(Ctl *c) {
 
 __global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
   __shared__ Cand lds[17];
+  const KC k = load_kc(c);
   if (c->done != D_RUN) return;
-  Cand pr = dev_price(c, c->cost1, 1.0, lds);
+  Cand pr = dev_price(k, c->cost1, 1.0, lds);
   if (pr.idx == 0) {
     dev_finish(c, D_NOFEAS, PH_PHASE1, c->rounds);
     return;
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
     dev_finish(c, D_ITLIM, PH_PHASE1, c->rounds);
     return;
   }
-  if (!dev_primal_step(c, pr.idx, pr.aux, c->gflag, lds)) dev_finish(c, D_FAIL, PH_PHASE1, c->rounds);
+  if (!dev_primal_step(k, c, pr.idx, pr.aux, c->gflag, lds)) dev_finish(c, D_FAIL, PH_PHASE1, c->rounds);
 }
 
 // ---------------------------------------------------------------------------- k_update
@@ -413,33 +437,47 @@ __global__ __launch_bounds__(256) void k_update(Ctl *c) {
     if (c->budget > 0) c->budget--;
   }
   const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
-  if (j0 > n) return;
+  const int i0 = (int)blockIdx.y * TR;
+  // a batched launch is sized for its largest slot: blocks wholly outside this slot's tableau leave;
+  // a block that straddles row m streams on into the spare rows every slab keeps behind it (ROW_SPARE)
+  if (j0 > n || i0 > m) return;
   const double2 s = *reinterpret_cast<const double2 *>(c->srow + j0);
   const bool q0 = (j0 == q), q1 = (j0 + 1 == q);
-  const int i0 = (int)blockIdx.y * TR;
   double *base = c->T + (size_t)i0 * ld + j0;
   const double *colq = c->colq + i0;
+  // straight-line stream (same shape as k_fb's hot path): every load issued before the first use
+  double2 v[TR];
+  double ci[TR];
+#pragma unroll
+  for (int r = 0; r < TR; r++) v[r] = *reinterpret_cast<const double2 *>(base + (size_t)r * ld);
+#pragma unroll
+  for (int r = 0; r < TR; r++) ci[r] = colq[r];
 #pragma unroll
   for (int r = 0; r < TR; r++) {
-    const int i = i0 + r;
-    if (i > m) break;
-    double2 *ptr = reinterpret_cast<double2 *>(base + (size_t)r * ld);
-    double2 v = *ptr;
-    const double ci = colq[r];
-    if (i == p) {
-      v.x = -s.x;
-      v.y = -s.y;
-      if (q0) v.x = 1.0 / piv;
-      if (q1) v.y = 1.0 / piv;
-      if (j0 == 0) v.x = c->xq - s.x;
-    } else {
-      v.x = fma(-ci, s.x, v.x);
-      v.y = fma(-ci, s.y, v.y);
-      if (q0) v.x = ci / piv;
-      if (q1) v.y = ci / piv;
-    }
-    *ptr = v;
+    v[r].x = fma(-ci[r], s.x, v[r].x);
+    v[r].y = fma(-ci[r], s.y, v[r].y);
   }
+  if (q0 || q1) {
+#pragma unroll
+    for (int r = 0; r < TR; r++) {
+      const double qv = ci[r] / piv;
+      if (q0) v[r].x = qv;
+      if (q1) v[r].y = qv;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (p >= i0 && p < i0 + TR) {
+#pragma unroll
+    for (int r = 0; r < TR; r++) {
+      if (i0 + r == p) {
+        v[r].x = q0 ? 1.0 / piv : -s.x;
+        v[r].y = q1 ? 1.0 / piv : -s.y;
+        if (j0 == 0) v[r].x = c->xq - s.x;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TR; r++) *reinterpret_cast<double2 *>(base + (size_t)r * ld) = v[r];
 }
 
 // ---------------------------------------------------------------------------- k_rowcomb
@@ -954,8 +992,13 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
 void launch_select(Ctl *d_ctl, hipStream_t s, int slots) { hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl); }
 void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
   const int pairs = (n + 2) / 2;
-  dim3 grid((pairs + 255) / 256, (m + 1 + UPDATE_TR - 1) / UPDATE_TR, slots);
-  hipLaunchKernelGGL(k_update<UPDATE_TR>, grid, dim3(256), 0, s, d_ctl);
+  const long tiles = (pairs + 255) / 256;
+  // 16-row tiles once the launch still has >= 2048 workgroups, else 8, else 4 (latency-bound sizes)
+  const int tr = ((long)((m + 16) / 16) * tiles * slots >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * slots >= 2048) ? 8 : 4;
+  dim3 grid((unsigned)tiles, (m + tr) / tr, slots);
+  if (tr == 16) hipLaunchKernelGGL(k_update<16>, grid, dim3(256), 0, s, d_ctl);
+  else if (tr == 8) hipLaunchKernelGGL(k_update<8>, grid, dim3(256), 0, s, d_ctl);
+  else hipLaunchKernelGGL(k_update<4>, grid, dim3(256), 0, s, d_ctl);
 }
 void launch_p1_head(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_head, dim3(1), dim3(1024), 0, s, d_ctl); }
 void launch_p1_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_select, dim3(1), dim3(1024), 0, s, d_ctl); }
