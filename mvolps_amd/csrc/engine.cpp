@@ -669,7 +669,6 @@ static bool job_finalize(SolveJob &J) {
 
 // the job's stream has been synchronised; returns true when the solve is complete
 static bool job_collect(Context &c, SolveJob &J) {
-  mvx_prob *P = J.P;
   SolveCtx &sc = *J.sc;
   Ctl &snap = J.snap;
   std::memcpy(&snap, sc.h_stage, sizeof(Ctl));

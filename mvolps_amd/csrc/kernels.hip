@@ -4,12 +4,16 @@
 // geometry from there, and returns at once when the solve has already finished
 // (ctl->done), so the host can queue pivots ahead without a round trip per pivot.
 //
-// One simplex pivot = k_select (one 1024-thread workgroup: pricing, ratio test, pivot-row
-// scaling; wave64 shuffle reductions + LDS across the 16 waves) followed by k_update (the
-// HBM-bound Gauss-Jordan rank-1 update streamed over the whole tableau, 16 bytes per lane).
+// Two pivot pipelines share the arithmetic:
+//   generic   k_select (one 1024-thread workgroup: the driver's state machine, pricing, ratio tests,
+//             pivot-row scaling; wave64 shuffle reductions + LDS across the 16 waves) then k_update
+//             (the HBM-bound Gauss-Jordan rank-1 update, 16 bytes per lane).  Serves the dual simplex,
+//             phase 1, the first step of every call, and -- launched once with grid.z = slots -- all
+//             handles of a batched solve (B&B children / windows).
+//   fused     k_fa / k_fb: primal phase 2 with no single-workgroup stage (large dense LPs).
 //
-// Arithmetic is mirrored operation-for-operation by oracle/mvolps_oracle.c; compiled with
-// -ffp-contract=off so fma() appears exactly where written.
+// Arithmetic is mirrored operation-for-operation by the CPU checker (oracle/mvolps_oracle.c, test
+// infrastructure); compiled with -ffp-contract=off so fma() appears exactly where written.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -596,24 +600,6 @@ __device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, C
   return true;
 }
 
-// wave-level reduce of an array of partials, result broadcast to all lanes
-template <int MODE>
-__device__ __forceinline__ Cand wave_reduce_partials(const Cand *arr, int cnt) {
-  const int lane = TIDX & 63;
-  Cand b{0.0, 0.0, 0, 0};
-  for (int k = lane; k < cnt; k += 64) {
-    Cand x = arr[k];
-    if (cand_better<MODE>(x, b)) b = x;
-  }
-  b = wave_best<MODE>(b);
-  Cand r;
-  r.k1 = __shfl(b.k1, 0, 64);
-  r.k2 = __shfl(b.k2, 0, 64);
-  r.idx = __shfl(b.idx, 0, 64);
-  r.aux = __shfl(b.aux, 0, 64);
-  return r;
-}
-
 // bootstrap: price the current objective row into pp[0]; arm the fused path
 __global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
   __shared__ Cand lds[17];
@@ -956,7 +942,6 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 }
 
 // ------------------------------------------------------------------ launch wrappers
-constexpr int UPDATE_TR = 16;
 
 // tuning knobs of the streamed update (mvx_set_tuning; defaults are the measured best)
 static int g_tr = 0, g_hot = 1, g_nt = 0; // g_tr 0 = pick from the grid size

@@ -71,8 +71,6 @@ struct Ctl {
   double ent_lb, ent_ub;
 };
 
-struct HostModel; // forward
-
 // shared immutable matrix row (1-based, n+1 doubles)
 using RowPtr = std::shared_ptr<std::vector<double>>;
 

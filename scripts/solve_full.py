@@ -12,10 +12,14 @@ mvolps_amd.require_device()
 for (m, n, seed) in [(1024, 2048, 12345), (4096, 8192, 12345)]:
     A, b, c = synth.dense_lp(m, n, seed)
     P = api.create()
+    t = time.perf_counter()
     P.load_dense(A, b, c)
-    P.simplex(it_lim=0)
+    P.simplex(it_lim=0)  # builds the tableau on the host and uploads it (PCIe)
+    api.sync()
+    t_up = time.perf_counter() - t
     t = time.perf_counter()
     rc = P.simplex()
     el = time.perf_counter() - t
     print(json.dumps({"m": m, "n": n, "seed": seed, "rc": rc, "status": P.status, "obj": P.obj, "pivots": P.it_cnt,
-                      "secs": el, "pivots_per_s": P.it_cnt / el, "device_ms": api.last_solve_ms(P.h)}), flush=True)
+                      "secs": el, "pivots_per_s": P.it_cnt / el, "load_build_upload_secs": t_up,
+                      "pivots_per_s_incl_upload": P.it_cnt / (el + t_up), "device_ms": api.last_solve_ms(P.h)}), flush=True)
