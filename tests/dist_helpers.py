@@ -85,3 +85,30 @@ def run_world(world, case, kw, outdir, use_gpu=False, port=None):
     port = port or (29500 + (os.getpid() % 2000))
     mp.spawn(_worker, args=(world, port, outdir, case, kw, use_gpu), nprocs=world, join=True)
     return [json.load(open(os.path.join(outdir, "rank%d.json" % r))) for r in range(world)]
+
+
+def _nccl_world1(rank, port, outdir, case, kw):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from mvolps_amd import dist_bnb, synth
+    from tests import lpgen
+
+    eng = dist_bnb.HipNodeEngine(0)  # device tensors: the collectives below run through RCCL
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        A, b, c, U = synth.dense_ilp(*case)
+        res = dist_bnb.branch_and_bound(eng, lpgen.load_ilp(eng.api, A, b, c, U), **kw)
+        with open(os.path.join(outdir, "nccl.json"), "w") as f:
+            json.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_nccl_world1(case, kw, outdir, port=None):
+    import torch.multiprocessing as mp
+
+    port = port or (31500 + (os.getpid() % 2000))
+    mp.spawn(_nccl_world1, args=(port, outdir, case, kw), nprocs=1, join=True)
+    return json.load(open(os.path.join(outdir, "nccl.json")))

@@ -51,3 +51,14 @@ def test_two_ranks_one_gpu_match_serial(gpu, tmp_path):
     for r in res:
         for k in ("n_nodes", "parent", "prune", "count", "events", "node_bound", "x", "total_pivots", "incumbent_oid", "best_lower"):
             assert r[k] == serial[k], k
+
+
+def test_coordinator_over_rccl_world1(gpu, tmp_path):
+    """backend "nccl" (= RCCL) with one rank on the one GPU: the MAX all-reduces and the incumbent
+    broadcast run on device tensors through RCCL; result equals the serial driver's."""
+    case = (8, 16, 3, 2)
+    A, b, c, U = synth.dense_ilp(*case)
+    serial = json.loads(json.dumps(bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=0, window=1)))
+    r = dist_helpers.run_nccl_world1(case, dict(quirks=0, per_rank=4), str(tmp_path))
+    for k in ("n_nodes", "parent", "prune", "count", "events", "node_bound", "x", "total_pivots", "incumbent_oid", "best_lower"):
+        assert r[k] == serial[k], k
