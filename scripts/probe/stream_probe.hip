@@ -38,6 +38,38 @@ __global__ __launch_bounds__(THREADS, MINW) void k(double *T, const double *c, c
     for (int u = 0; u < CPL / 2; u++) *reinterpret_cast<double2 *>(base + (size_t)r * ld + 2 * u) = v[r][u];
 }
 
+// pivot-column tile (TR doubles) staged through LDS: one wave loads it, every lane reads it back
+template <int THREADS, int TR>
+__global__ __launch_bounds__(THREADS) void k_lds(double *T, const double *c, const double *s, int rows, int ld) {
+  __shared__ double cs[TR];
+  const int i0 = (int)blockIdx.y * TR;
+  if (threadIdx.x < TR) cs[threadIdx.x] = c[i0 + threadIdx.x];
+  const int j0 = 2 * ((int)blockIdx.x * THREADS + (int)threadIdx.x);
+  const bool act = j0 < ld;
+  double2 sv = act ? *reinterpret_cast<const double2 *>(s + j0) : double2{0, 0};
+  double *base = T + (size_t)i0 * ld + j0;
+  double2 v[TR];
+  if (act) {
+#pragma unroll
+    for (int r = 0; r < TR; r++) v[r] = *reinterpret_cast<const double2 *>(base + (size_t)r * ld);
+  }
+  __syncthreads();
+  if (!act) return;
+#pragma unroll
+  for (int r = 0; r < TR; r++) {
+    const double ci = cs[r];
+    v[r].x = fma(-ci, sv.x, v[r].x);
+    v[r].y = fma(-ci, sv.y, v[r].y);
+  }
+#pragma unroll
+  for (int r = 0; r < TR; r++) *reinterpret_cast<double2 *>(base + (size_t)r * ld) = v[r];
+}
+template <int THREADS, int TR>
+void launch_lds(double *T, const double *c, const double *s, int rows, int ld, hipStream_t st) {
+  dim3 grid((ld / 2 + THREADS - 1) / THREADS, rows / TR);
+  hipLaunchKernelGGL((k_lds<THREADS, TR>), grid, dim3(THREADS), 0, st, T, c, s, rows, ld);
+}
+
 struct Var { const char *name; void (*launch)(double *, const double *, const double *, int, int, hipStream_t); };
 template <int THREADS, int TR, int CPL, int MINW>
 void launch(double *T, const double *c, const double *s, int rows, int ld, hipStream_t st) {
@@ -60,6 +92,7 @@ int main() {
     {"t256 tr8  cpl4 w1", launch<256, 8, 4, 1>},  {"t256 tr16 cpl4 w1", launch<256, 16, 4, 1>}, {"t256 tr4  cpl4 w1", launch<256, 4, 4, 1>},
     {"t512 tr16 cpl2 w1", launch<512, 16, 2, 1>}, {"t512 tr8  cpl2 w1", launch<512, 8, 2, 1>},  {"t128 tr16 cpl2 w1", launch<128, 16, 2, 1>},
     {"t128 tr32 cpl2 w1", launch<128, 32, 2, 1>}, {"t256 tr32 cpl2 w1", launch<256, 32, 2, 1>}, {"t64  tr16 cpl4 w1", launch<64, 16, 4, 1>},
+    {"t256 tr16 LDS colq", launch_lds<256, 16>}, {"t128 tr16 LDS colq", launch_lds<128, 16>}, {"t256 tr32 LDS colq", launch_lds<256, 32>},
     {"t256 tr12 cpl2 w1", launch<256, 12, 2, 1>}, {"t1024 tr8 cpl2 w1", launch<1024, 8, 2, 1>}, {"t256 tr8  cpl8 w1", launch<256, 8, 8, 1>},
   };
   const double bytes = 16.0 * rows * ld;
