@@ -571,12 +571,13 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       break;
     }
     const size_t W = std::min(leafContainer.size(), (size_t)prm.window);
-    // A. clone + solve the window (bs.cpp:114-117)
+    // A. solve the window (bs.cpp:114-117).  The reference copies the node's problem into the scratch
+    // `a` and solves the copy; the node is discarded after this step either way, so its own clone is
+    // solved in place here -- same state, one device-to-device clone fewer per node.
     std::vector<void *> a(W);
     std::vector<int> before(W);
     for (size_t w = 0; w < W; w++) {
-      a[w] = api->create_prob();
-      api->copy_prob(a[w], leafContainer[w]->prob, MVX_OFF);
+      a[w] = leafContainer[w]->prob;
       before[w] = api->get_it_cnt(a[w]);
     }
     api->simplex_batch(a.data(), (int)W, nullptr, nullptr);
@@ -691,10 +692,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       rec.emit(MVX_EV_CANDIDATE, br.S3->oid, br.S3->upperBound, 0.0, 0, 0);
     }
     rec.sink = nullptr;
-    for (size_t w = 0; w < W; w++) {
-      rec.events.insert(rec.events.end(), node_events[w].begin(), node_events[w].end());
-      api->delete_prob(a[w]);
-    }
+    for (size_t w = 0; w < W; w++) rec.events.insert(rec.events.end(), node_events[w].begin(), node_events[w].end());
     leafContainer.erase(leafContainer.begin(), leafContainer.begin() + (long)processed);
   }
   leafContainer.clear();

@@ -18,7 +18,7 @@ def same(g, o):
     return all(np.array_equal(x, y) for x, y in zip(g.basis(), o.basis()))
 
 t0 = time.time()
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 n_gen = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 for k in range(n_gen):
     A, row_b, col_b, c, direction = lpgen.random_general_lp(rng, mmax=30, nmax=40)
