@@ -153,8 +153,9 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         for w, nd in enumerate(window):
             if nd.owner != rank:
                 continue
-            a = api.create()
-            api.copy_prob(a.h, local[nd.oid].h, capi.OFF)
+            # bs.cpp:114-116 copies the node's problem into a scratch and solves the copy; the node is
+            # discarded after this round either way, so its own clone is solved in place
+            a = local[nd.oid]
             mine.append((w, nd, a, a.it_cnt))
         engine.solve_many([a for (_, _, a, _) in mine])
         for w, nd, a, before in mine:
