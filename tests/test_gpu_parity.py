@@ -318,4 +318,49 @@ def test_both_primal_pipelines_bit_exact(gpu, orc, pipeline):
             P.simplex()
         assert_same_state(g2, o2, "pipeline %d boxed" % pipeline)
     finally:
-        gpu.use_pipeline(1)
+        gpu.use_pipeline(0)
+
+
+def test_tall_tableau_dual_path_bit_exact(gpu, orc):
+    """A tableau taller than one k_select pass (m > 1024 lanes): warm-started children (bs.cpp:274-288)
+    one by one and through mvx_simplex_batch, then a grandchild, against the oracle -- the dual simplex
+    with multi-pass row scans and 8-row update tiles."""
+    import ctypes as C
+
+    A, b, c, U = synth.dense_ilp(1100, 300, seed=21, U=3)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    assert_same_state(g, o, "tall root")
+    x = o.col_prim()
+    frac = [j + 1 for j in range(len(x)) if np.trunc(x[j]) != x[j]]
+    assert len(frac) >= 2
+    kids_g, kids_o = [], []
+    for j in frac[:3]:
+        for (t, lo, hi) in ((UP, 0.0, float(np.floor(x[j - 1]))), (LO, float(np.ceil(x[j - 1])), 0.0)):
+            for P, kids in ((g, kids_g), (o, kids_o)):
+                ch = P.copy()
+                P.api.set_col_bnds(ch.h, j, t, lo, hi)
+                kids.append(ch)
+    # first two children one by one, the rest as a batch
+    for kg, ko in zip(kids_g[:2], kids_o[:2]):
+        assert kg.simplex() == ko.simplex()
+        assert kg.it_cnt > g.it_cnt  # the dual simplex really pivoted
+        assert_same_state(kg, ko, "tall child")
+    rest_g, rest_o = kids_g[2:], kids_o[2:]
+    arr = (C.c_void_p * len(rest_g))(*[k.h for k in rest_g])
+    rcs = (C.c_int * len(rest_g))()
+    assert gpu.simplex_batch(arr, len(rest_g), None, rcs) == 0
+    for kg, ko in zip(rest_g, rest_o):
+        ko.simplex()
+        assert_same_state(kg, ko, "tall batched child")
+    # grandchildren: a second bound change on an already re-solved child
+    xg = kids_o[0].col_prim()
+    frac2 = [j + 1 for j in range(len(xg)) if np.trunc(xg[j]) != xg[j]]
+    if frac2:
+        j = frac2[-1]
+        for P in (kids_g[0], kids_o[0]):
+            P.api.set_col_bnds(P.h, j, LO, float(np.ceil(xg[j - 1])), 0.0)
+            P.simplex()
+        assert_same_state(kids_g[0], kids_o[0], "tall grandchild")
