@@ -77,7 +77,7 @@ typedef struct {
   int window;           /* FIFO order without cuts, engine with a batch entry: solve the front `window`
                            nodes of the deque together and replay bs.cpp's decisions in queue order --
                            same tree, oids, events and incumbent as node-at-a-time;
-                           default 32, 1 = node at a time */
+                           default 64, 1 = node at a time */
 } mvx_bnb_params;
 
 /* B&B events at the emit points of bs.cpp (message.h EventType) */

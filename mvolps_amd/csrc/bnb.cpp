@@ -223,7 +223,18 @@ struct NodeData { // util.h:35-54
     _api->copy_prob(prob, parent, MVX_ON);
     inital = false;
   }
-  ~NodeData() { _api->delete_prob(prob); } // util.cpp:39-42
+  // adopts `owned` instead of cloning it: the state a clone would have, without the device-to-device copy
+  NodeData(const mvx_lp_api *api, void *owned, int &idCounter, bool /*adopt*/) : _api(api) {
+    oid = idCounter;
+    idCounter += 1;
+    lowerBound = -std::numeric_limits<double>::infinity();
+    upperBound = std::numeric_limits<double>::infinity();
+    prob = owned;
+    inital = false;
+  }
+  ~NodeData() {
+    if (prob) _api->delete_prob(prob); // util.cpp:39-42
+  }
   NodeData(const NodeData &) = delete;
   NodeData &operator=(const NodeData &) = delete;
   double upperBound, lowerBound;
@@ -639,18 +650,22 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
         rec.emit(MVX_EV_BRANCHED, node->oid, node->upperBound, acc, (int)vars.size(), pick);
         Branch br;
         br.slot = w;
+        // bs.cpp:269-273 clones the solved node twice.  The node itself is dropped at the end of this
+        // round, so the second child takes over its problem object instead of cloning it (same state,
+        // one device-to-device tableau copy fewer per branching).
+        const double bound = api->get_col_prim(aw, pick);
+        const int t = api->get_col_type(aw, pick);
+        const double l = api->get_col_lb(aw, pick), u = api->get_col_ub(aw, pick);
         br.S2 = std::make_shared<MVOLP::NodeData>(api, aw, id); // even oid (R), then odd (L): bs.cpp:43-52
-        br.S3 = std::make_shared<MVOLP::NodeData>(api, aw, id);
+        br.S3 = std::make_shared<MVOLP::NodeData>(api, aw, id, true);
+        node->prob = nullptr;
         rec.node(br.S2->oid, node->oid);
         rec.node(br.S3->oid, node->oid);
-        // same bounds as mvx_bnb_make_children, on the NodeData clones
-        const double bound = api->get_col_prim(aw, pick);
+        // same bounds as mvx_bnb_make_children
         if (quirks) {
           api->set_col_bnds(br.S2->prob, pick, MVX_UP, 0, std::floor(bound));
           api->set_col_bnds(br.S3->prob, pick, MVX_LO, std::ceil(bound), 0);
         } else {
-          const int t = api->get_col_type(aw, pick);
-          const double l = api->get_col_lb(aw, pick), u = api->get_col_ub(aw, pick);
           if (t == MVX_LO || t == MVX_DB || t == MVX_FX)
             api->set_col_bnds(br.S2->prob, pick, (l == std::floor(bound)) ? MVX_FX : MVX_DB, l, std::floor(bound));
           else
@@ -749,7 +764,7 @@ void mvx_bnb_default_params(mvx_bnb_params *p) {
   p->reference_quirks = 1;
   p->lazy_pool = 1;
   p->cut_select = 0;
-  p->window = 32;
+  p->window = 64;
 }
 
 int mvx_branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params *params, mvx_bnb_result *res) {
