@@ -152,10 +152,6 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf);
 /* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
    for measurement sweeps -- results are identical for every setting */
 void mvx_set_tuning(int tr, int hot, int nt);
-/* 1: primal phase 2 as ONE launch per pivot (k_fs: out-of-place update overlapped with selector
-   workgroups); 0 (default): the two-kernel k_fa / k_fb pair.  Results are identical; the single launch
-   measured slower on MI355X ("Single-launch pipeline") and is kept as a tested variant */
-void mvx_use_pipeline(int on);
 /* replay each batch of queued pivots as one captured hipGraph instead of eager launches (default
    off: measured no gain on MI355X -- small-kernel dispatch is command-processor-bound) */
 void mvx_use_graphs(int on);

@@ -32,8 +32,6 @@ int fused_nrb_max(int m);
 void launch_fboot(Ctl *, int n, hipStream_t);
 void launch_fa(Ctl *, int n, hipStream_t);
 void launch_fb(Ctl *, int m, int n, hipStream_t);
-void launch_fsboot(Ctl *, int m, hipStream_t);
-void launch_fs(Ctl *, int m, int n, int par, hipStream_t);
 void launch_select(Ctl *, hipStream_t, int slots = 1);
 void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1);
 void launch_p1_head(Ctl *, hipStream_t);
@@ -62,11 +60,6 @@ struct SolveCtx {
   int *d_gflag = nullptr;
   double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
-  double *d_srow2[2] = {nullptr, nullptr};
-  unsigned long long *d_fsp = nullptr;
-  unsigned int *d_fscnt = nullptr;
-  double *d_T2 = nullptr; // shadow tableau of the single-launch pipeline (k_fs), grown on demand
-  size_t T2_bytes = 0;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
   size_t stage_bytes = 0;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -95,7 +88,6 @@ struct Context {
 };
 
 static Context *g_ctx = nullptr;
-static bool g_pipeline = false;   // true: single-launch primal pipeline (k_fs, measured slower -- DESIGN.md); false: the k_fa / k_fb pair
 static bool g_use_graphs = false; // measured: no gain (dispatch is command-processor-bound, not host-bound)
 static int g_requested_dev = -1;
 
@@ -172,8 +164,6 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_bc0 = carve((size_t)(mc + 1) * 8), o_bc1 = carve((size_t)(mc + 1) * 8);
   size_t o_pp0 = carve((size_t)fused_npb(l) * sizeof(Cand)), o_pp1 = carve((size_t)fused_npb(l) * sizeof(Cand));
   size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
-  size_t o_s20 = carve((size_t)l * 8), o_s21 = carve((size_t)l * 8);
-  size_t o_fsp = carve((size_t)FS_MAX_SEL * 5 * 8), o_fsc = carve(64);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -191,25 +181,11 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_pp[0] = (Cand *)(b + o_pp0);
   sc.d_pp[1] = (Cand *)(b + o_pp1);
   sc.d_rp = (Cand *)(b + o_rp);
-  sc.d_srow2[0] = (double *)(b + o_s20);
-  sc.d_srow2[1] = (double *)(b + o_s21);
-  sc.d_fsp = (unsigned long long *)(b + o_fsp);
-  sc.d_fscnt = (unsigned int *)(b + o_fsc);
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
   sc.sc_m_cap = mc;
   sc.sc_ld = l;
-}
-
-// shadow tableau for the out-of-place pipeline: as large as the largest handle solved through it
-static void ensure_shadow(SolveCtx &sc, const mvx_prob *P) {
-  const size_t need = (size_t)(P->m_cap + 1) * P->ld * 8;
-  if (need <= sc.T2_bytes) return;
-  HIPCHECK(hipStreamSynchronize(sc.stream));
-  if (sc.d_T2) HIPCHECK(hipFree(sc.d_T2));
-  HIPCHECK(hipMalloc((void **)&sc.d_T2, need));
-  sc.T2_bytes = need;
 }
 
 // ------------------------------------------------------------------------------- slabs
@@ -385,10 +361,6 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
   h->npb = fused_npb(P->n); h->nrb = 0; // nrb is published by k_fb (its grid height)
   h->fstate = F_OFF;
-  h->T2 = sc.d_T2;
-  h->srow2[0] = sc.d_srow2[0]; h->srow2[1] = sc.d_srow2[1];
-  h->fsp = sc.d_fsp; h->fscnt = sc.d_fscnt;
-  h->fs[0].step = ST_STOP; h->fs[1].step = ST_STOP;
 }
 
 static void upload_ctl(SolveCtx &sc) {
@@ -530,7 +502,6 @@ struct SolveJob {
   size_t ev_used = 0;
   bool profiled = false;
   int rc = 0;
-  int fs_launches = 0; // k_fs launches queued by the last batch (0: none)
   Ctl snap;
 };
 
@@ -549,7 +520,6 @@ static void job_begin(Context &c, SolveJob &J) {
   mvx_prob *P = J.P;
   SolveCtx &sc = *J.sc;
   ensure_scratch(sc, P->m_cap, P->ld);
-  if (g_pipeline && !P->hint_dual) ensure_shadow(sc, P);
   Ctl *h = sc.h_ctl;
   fill_ctl(sc, P, h);
   h->tol_bnd = J.parm.tol_bnd;
@@ -585,7 +555,6 @@ static void job_enqueue(Context &c, SolveJob &J) {
     return;
   }
   const int batch = J.batch;
-  J.fs_launches = 0;
   if (J.profiled && c.ev_pool.size() < (size_t)2 * batch + 2) { // sized for the largest batch
     size_t old = c.ev_pool.size();
     c.ev_pool.resize((size_t)2 * batch + 2);
@@ -618,18 +587,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
       ev();
       launch_update(sc.d_ctl, m_grid, n, sc.stream);
       ev();
-      if (depth > 0 && g_pipeline && sc.d_T2 && sc.T2_bytes >= (size_t)(P->m_cap + 1) * P->ld * 8) {
-        // one launch per pivot: launch k applies step k out of place while its selector workgroup
-        // chooses step k+1; the first launch applies nothing and only selects
-        launch_fsboot(sc.d_ctl, m_grid, sc.stream);
-        launch_fs(sc.d_ctl, m_grid, n, 0, sc.stream);
-        for (int k = 1; k <= depth; k++) {
-          ev();
-          launch_fs(sc.d_ctl, m_grid, n, k & 1, sc.stream);
-          ev();
-        }
-        J.fs_launches = depth + 1;
-      } else if (depth > 0) {
+      if (depth > 0) {
         launch_fboot(sc.d_ctl, n, sc.stream);
         launch_fb(sc.d_ctl, m_grid, n, sc.stream);
         for (int k = 0; k < depth; k++) {
@@ -749,14 +707,6 @@ static bool job_collect(Context &c, SolveJob &J) {
   J.done = snap.done;
   J.seen_pivots = snap.it_cnt;
   J.try_fused = (snap.phase == PH_PRIMAL2);
-  if (J.fs_launches > 0) {
-    // the descriptor the next launch would have read says which buffer holds the tableau; the generic
-    // kernels and every other entry point work on the handle's own buffer, so bring it home
-    const FsDesc &nd = snap.fs[J.fs_launches & 1];
-    if (nd.tsrc == 1)
-      HIPCHECK(hipMemcpyAsync(J.P->d_T, sc.d_T2, (size_t)(J.P->m + 1) * J.P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
-    J.fs_launches = 0;
-  }
   if (J.done == D_NEED_PHASE1) {
     snap.done = D_RUN;
     snap.phase = PH_PHASE1;
@@ -1303,7 +1253,6 @@ void tuning(int tr, int hot, int nt) {
 }
 
 void use_graphs(int on) { g_use_graphs = on != 0; }
-void use_pipeline(int on) { g_pipeline = on != 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }
 void profile_enable(int on) { ctx().prof = on != 0; }
 void profile_reset() {

@@ -941,371 +941,6 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   }
 }
 
-// =========================================================== single-launch primal pipeline
-// ONE launch per primal phase-2 pivot.  Launch k applies step k out of place (reads one tableau
-// buffer, writes the other) while a few selector workgroups choose step k+1 from the buffer being
-// read: every entry of the tableau AFTER step k is a rank-1 correction of an entry before it,
-//   new(i,j) = fma(-colq_k[i], srow_k[j], old(i,j))   (row p_k / column q_k: the pivot formulas),
-// so the ratio test (one column), the next pivot row and the pricing of the step after need O(m+n)
-// old entries, not the updated tableau.  The selector workgroups split the strided column gather,
-// publish one partial each (8-byte agent-scope atomics) and the last one to arrive finishes the
-// selection alone -- all of it behind the HBM stream of the other workgroups, reading nothing that
-// this launch writes.  Arithmetic is entry for entry that of k_select / k_update.
-__device__ __forceinline__ int fs_selectors(int m) {
-  int s = (m + 1 + 127) / 128;
-  return s < 1 ? 1 : (s > FS_MAX_SEL ? FS_MAX_SEL : s);
-}
-__device__ __forceinline__ unsigned long long d2u(double x) { return (unsigned long long)__double_as_longlong(x); }
-__device__ __forceinline__ double u2d(unsigned long long x) { return __longlong_as_double((long long)x); }
-
-template <int TR>
-__global__ __launch_bounds__(256) void k_fs(Ctl *c, int par) {
-  const FsDesc d = c->fs[par];
-  if (c->done != D_RUN) return;
-  const int m = c->m, n = c->n;
-  const size_t ld = (size_t)c->ld;
-  double *const src = d.tsrc ? c->T2 : c->T;
-  const double *const colqk = c->colqx[par];
-  const double *const srowk = c->srow2[par];
-  const int S = fs_selectors(m);
-  const int L = (int)blockIdx.x;
-  if (L >= S) {
-    // ---- streaming workgroups: step k, out of place
-    if (d.step != ST_PIVOT) return;
-    double *const dst = d.tsrc ? c->T : c->T2;
-    const int tiles_x = (((n + 2) / 2) + 255) / 256;
-    const int tx = (L - S) % tiles_x, ty = (L - S) / tiles_x;
-    const int j0 = 2 * (tx * 256 + TIDX);
-    const int i0 = ty * TR;
-    if (j0 > n || i0 > m) return;
-    const double2 s = *reinterpret_cast<const double2 *>(srowk + j0);
-    const bool q0 = (j0 == d.q), q1 = (j0 + 1 == d.q);
-    const double *sb = src + (size_t)i0 * ld + j0;
-    double *db = dst + (size_t)i0 * ld + j0;
-    double2 v[TR];
-    double ci[TR];
-#pragma unroll
-    for (int r = 0; r < TR; r++) v[r] = *reinterpret_cast<const double2 *>(sb + (size_t)r * ld);
-#pragma unroll
-    for (int r = 0; r < TR; r++) ci[r] = colqk[i0 + r];
-#pragma unroll
-    for (int r = 0; r < TR; r++) {
-      v[r].x = fma(-ci[r], s.x, v[r].x);
-      v[r].y = fma(-ci[r], s.y, v[r].y);
-    }
-    if (q0 || q1) {
-#pragma unroll
-      for (int r = 0; r < TR; r++) {
-        const double qv = ci[r] / d.piv;
-        if (q0) v[r].x = qv;
-        if (q1) v[r].y = qv;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (d.p >= i0 && d.p < i0 + TR) {
-#pragma unroll
-      for (int r = 0; r < TR; r++) {
-        if (i0 + r == d.p) {
-          v[r].x = q0 ? 1.0 / d.piv : -s.x;
-          v[r].y = q1 ? 1.0 / d.piv : -s.y;
-          if (j0 == 0) v[r].x = d.xq - s.x;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < TR; r++) *reinterpret_cast<double2 *>(db + (size_t)r * ld) = v[r];
-    return;
-  }
-  // ---- selector workgroups
-  __shared__ Cand lds[17];
-  __shared__ double sh_a[5], sh_b[5];
-  __shared__ int sh_last;
-  FsDesc *const out = &c->fs[par ^ 1];
-  if (d.step == ST_STOP) {
-    if (L == 0 && TIDX == 0) {
-      out->step = ST_STOP;
-      out->tsrc = d.tsrc;
-    }
-    return;
-  }
-  const bool pivk = (d.step == ST_PIVOT), flipk = (d.step == ST_FLIP);
-  const double tp = c->tol_piv, tol = c->tol_dj, sgn = c->sgn;
-  const double s0 = pivk ? srowk[0] : 0.0;
-  double *const colqn = c->colqx[par ^ 1];
-  double *const srown = c->srow2[par ^ 1];
-  const double *const bold = c->betac[par];
-  double *const bnew = c->betac[par ^ 1];
-  const int tnext = pivk ? (d.tsrc ^ 1) : d.tsrc;
-  const int qn = d.qn, sdn = d.sdn;
-  // entry (i,j) of the tableau after step k, from the entry `told` before it
-  auto entry = [&](int i, int j, double told) -> double {
-    if (!pivk) return told;
-    if (i == d.p) return (j == d.q) ? 1.0 / d.piv : (j == 0 ? d.xq - s0 : -srowk[j]);
-    if (j == d.q) return colqk[i] / d.piv;
-    return fma(-colqk[i], srowk[j], told);
-  };
-  // 1. this workgroup's slice of rows: new basic values (exported; written back for a flip) and, when a
-  //    next entering column exists, its new entries (exported) + the slice's ratio-test partial
-  const int rows_per = (m + 1 + S - 1) / S;
-  const int r0 = L * rows_per, r1 = (r0 + rows_per - 1 < m) ? r0 + rows_per - 1 : m;
-  Cand rb{0.0, 0.0, 0, 0};
-  double rb_a = 0.0, rb_beta = 0.0;
-  for (int i = r0 + TIDX; i <= r1; i += 256) {
-    double beta;
-    if (pivk) beta = (i == d.p) ? d.xq - s0 : fma(-colqk[i], s0, bold[i]);
-    else if (flipk) {
-      beta = fma(colqk[i], d.delta, bold[i]);
-      src[(size_t)i * ld] = beta;
-    } else beta = bold[i];
-    bnew[i] = beta;
-    if (qn == 0) continue;
-    const double a = entry(i, qn, src[(size_t)i * ld + qn]);
-    colqn[i] = a;
-    if (i == 0) continue;
-    const double lb = (pivk && i == d.p) ? d.ent_lb : c->blb[i];
-    const double ub = (pivk && i == d.p) ? d.ent_ub : c->bub[i];
-    Cand x;
-    if (ratio_row(a, sdn, beta, lb, ub, 0, tp, i, x) && cand_better<1>(x, rb)) {
-      rb = x;
-      rb_a = a;
-      rb_beta = beta;
-    }
-  }
-  // block-wide best with its payload
-  {
-    const Cand w = block_best<1>(rb, lds);
-    if (rb.idx == w.idx && w.idx != 0) { // the owner of the winning row publishes the payload
-      sh_a[0] = rb_a;
-      sh_b[0] = rb_beta;
-    }
-    __syncthreads();
-    rb = w;
-    rb_a = sh_a[0];
-    rb_beta = sh_b[0];
-  }
-  // 2. publish the partial, find out who is last
-  if (TIDX == 0) {
-    unsigned long long *slot = c->fsp + (size_t)L * 5;
-    __hip_atomic_store(slot + 0, d2u(rb.k1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slot + 1, d2u(rb.k2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slot + 2, ((unsigned long long)(unsigned)rb.idx << 32) | (unsigned)rb.aux, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slot + 3, d2u(rb_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slot + 4, d2u(rb_beta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned old = __hip_atomic_fetch_add(c->fscnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh_last = (old == (unsigned)(S - 1)) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!sh_last) return;
-  // ---- the last selector workgroup to arrive finishes the selection alone
-  if (TIDX == 0) __hip_atomic_store(c->fscnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // non-basic data of column j as it stands after step k (the arrays are swapped at the very end)
-  auto nb_flag = [&](int j) -> int { return (pivk && j == d.q) ? d.leave_flag : (flipk && j == d.q) ? d.flipflag : c->nflag[j]; };
-  auto nb_lb = [&](int j) -> double { return (pivk && j == d.q) ? c->blb[d.p] : c->nlb[j]; };
-  auto nb_ub = [&](int j) -> double { return (pivk && j == d.q) ? c->bub[d.p] : c->nub[j]; };
-  auto finish_step_k = [&]() { // bookkeeping of step k; every reader of the old arrays has arrived
-    if (TIDX != 0) return;
-    if (pivk) {
-      const int kv = c->bvar[d.p];
-      const double klb = c->blb[d.p], kub = c->bub[d.p];
-      c->bvar[d.p] = c->nvar[d.q];
-      c->blb[d.p] = c->nlb[d.q];
-      c->bub[d.p] = c->nub[d.q];
-      c->nvar[d.q] = kv;
-      c->nlb[d.q] = klb;
-      c->nub[d.q] = kub;
-      c->nflag[d.q] = d.leave_flag;
-      c->it_cnt++;
-      if (c->budget > 0) c->budget--;
-    } else if (flipk) {
-      c->nflag[d.q] = d.flipflag;
-      c->n_flips++;
-    }
-  };
-  const int budget_after = (pivk && c->budget > 0) ? c->budget - 1 : c->budget;
-  if (qn == 0 || budget_after == 0) {
-    finish_step_k();
-    if (TIDX == 0) {
-      out->step = ST_STOP;
-      out->tsrc = tnext;
-    }
-    return;
-  }
-  // reduce the S partials: lane k fetches partial k (independent loads), block-wide arg-best
-  Cand best{0.0, 0.0, 0, 0};
-  double piv = 0.0, betap = 0.0;
-  {
-    Cand x{0.0, 0.0, 0, 0};
-    double xa = 0.0, xb = 0.0;
-    if ((int)TIDX < S) {
-      const unsigned long long *slot = c->fsp + (size_t)TIDX * 5;
-      const unsigned long long w0 = __hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long w1 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long w2 = __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long w3 = __hip_atomic_load(slot + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long w4 = __hip_atomic_load(slot + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      x.k1 = u2d(w0);
-      x.k2 = u2d(w1);
-      x.idx = (int)(w2 >> 32);
-      x.aux = (int)(unsigned)(w2 & 0xffffffffu);
-      xa = u2d(w3);
-      xb = u2d(w4);
-    }
-    best = block_best<1>(x, lds);
-    if (x.idx == best.idx && best.idx != 0) {
-      sh_a[1] = xa;
-      sh_b[1] = xb;
-    }
-    __syncthreads();
-    piv = sh_a[1];
-    betap = sh_b[1];
-  }
-  const double lbq = nb_lb(qn), ubq = nb_ub(qn);
-  const int fq = nb_flag(qn);
-  // row 0 after step k, and pricing helper for the step after next
-  const double dq = entry(0, qn, src[qn]);
-  int step_next = ST_PIVOT, flipflag_next = 0;
-  double delta_next = 0.0;
-  if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
-    const double tf = ubq - lbq;
-    if (best.idx == 0 || tf <= best.k1) {
-      step_next = ST_FLIP;
-      delta_next = (sdn > 0) ? tf : -tf;
-      flipflag_next = (sdn > 0) ? MVX_NU : MVX_NL;
-    }
-  }
-  if (step_next == ST_PIVOT && best.idx == 0) { // unbounded ray: the generic path reports it
-    finish_step_k();
-    if (TIDX == 0) {
-      out->step = ST_STOP;
-      out->tsrc = tnext;
-    }
-    return;
-  }
-  const int p = best.idx, p_up = best.aux;
-  double plb = 0.0, pub = 0.0, bound = 0.0;
-  int lf = 0;
-  Cand pb{0.0, 0.0, 0, 0};
-  // entry (i,j) after step k from preloaded operands (ci = colq_k[i], skj = srow_k[j]): same arithmetic as entry()
-  auto ent = [&](int i, double ci, int j, double told, double skj) -> double {
-    if (!pivk) return told;
-    if (i == d.p) return (j == d.q) ? 1.0 / d.piv : (j == 0 ? d.xq - s0 : -skj);
-    if (j == d.q) return ci / d.piv;
-    return fma(-ci, skj, told);
-  };
-  constexpr int U = 8; // columns per lane whose loads are all in flight before the first use
-  const double c0 = pivk ? colqk[0] : 0.0;
-  if (step_next == ST_PIVOT) {
-    plb = (pivk && p == d.p) ? d.ent_lb : c->blb[p];
-    pub = (pivk && p == d.p) ? d.ent_ub : c->bub[p];
-    bound = p_up ? pub : plb;
-    lf = dev_leave_flag(plb, pub, p_up);
-    const double cp = pivk ? colqk[p] : 0.0;
-    const double *rowp = src + (size_t)p * ld;
-    // next pivot row, scaled; objective row after step k+1; pricing of the step after
-    for (int jb = TIDX; jb <= n; jb += 256 * U) {
-      double tpv[U], t0v[U], skv[U];
-      int nfv[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int j = jb + u * 256;
-        const bool ok = j <= n;
-        tpv[u] = ok ? rowp[j] : 0.0;
-        t0v[u] = ok ? src[j] : 0.0;
-        skv[u] = (ok && pivk) ? srowk[j] : 0.0;
-        nfv[u] = ok ? c->nflag[j] : MVX_NS;
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int j = jb + u * 256;
-        if (j > n) continue;
-        const double v = (j == 0) ? betap : ent(p, cp, j, tpv[u], skv[u]);
-        const double sj = (j == 0) ? (v - bound) / piv : v / piv;
-        srown[j] = sj;
-        if (j >= 1) {
-          const double dnew = (j == qn) ? dq / piv : fma(-dq, sj, ent(0, c0, j, t0v[u], skv[u]));
-          const int f = (j == qn) ? lf : (pivk && j == d.q) ? d.leave_flag : (flipk && j == d.q) ? d.flipflag : nfv[u];
-          Cand x;
-          if (price_col(f, sgn * dnew, tol, j, x) && cand_better<0>(x, pb)) pb = x;
-        }
-      }
-    }
-  } else {
-    // bound flip next: objective row unchanged by it; column qn changes status
-    for (int jb = 1 + TIDX; jb <= n; jb += 256 * U) {
-      double t0v[U], skv[U];
-      int nfv[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int j = jb + u * 256;
-        const bool ok = j <= n;
-        t0v[u] = ok ? src[j] : 0.0;
-        skv[u] = (ok && pivk) ? srowk[j] : 0.0;
-        nfv[u] = ok ? c->nflag[j] : MVX_NS;
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int j = jb + u * 256;
-        if (j > n) continue;
-        const double dj = ent(0, c0, j, t0v[u], skv[u]);
-        const int f = (j == qn) ? flipflag_next : (pivk && j == d.q) ? d.leave_flag : (flipk && j == d.q) ? d.flipflag : nfv[u];
-        Cand x;
-        if (price_col(f, sgn * dj, tol, j, x) && cand_better<0>(x, pb)) pb = x;
-      }
-    }
-  }
-  pb = block_best<0>(pb, lds);
-  const double xq_next = dev_nb_value(fq, lbq, ubq);
-  finish_step_k();
-  if (TIDX == 0) {
-    out->step = step_next;
-    out->p = p;
-    out->q = qn;
-    out->sdir = sdn;
-    out->p_up = p_up;
-    out->piv = piv;
-    out->bound = bound;
-    out->xq = xq_next;
-    out->leave_flag = lf;
-    out->delta = delta_next;
-    out->flipflag = flipflag_next;
-    out->ent_lb = lbq;
-    out->ent_ub = ubq;
-    out->tsrc = tnext;
-    out->qn = pb.idx;
-    out->sdn = pb.aux;
-  }
-}
-
-// arms the pipeline after a generic step (one workgroup): contiguous copy of column 0, pricing of the
-// current objective row, first descriptor = "no step to apply"
-__global__ __launch_bounds__(1024) void k_fsboot(Ctl *c) {
-  __shared__ Cand lds[17];
-  const bool go = (c->done == D_RUN && c->phase == PH_PRIMAL2);
-  Cand best{0.0, 0.0, 0, 0};
-  if (go) {
-    const size_t ld = (size_t)c->ld;
-    for (int i = TIDX; i <= c->m; i += 1024) c->betac[0][i] = c->T[i * ld];
-    for (int j = 1 + TIDX; j <= c->n; j += 1024) {
-      Cand x;
-      if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, x) && cand_better<0>(x, best)) best = x;
-    }
-  }
-  best = block_best<0>(best, lds);
-  if (TIDX == 0) {
-    c->fs[0].step = go ? ST_NONE : ST_STOP;
-    c->fs[0].tsrc = 0;
-    c->fs[0].qn = best.idx;
-    c->fs[0].sdn = best.aux;
-    c->fs[1].step = ST_STOP;
-    c->fs[1].tsrc = 0;
-    *c->fscnt = 0u;
-    c->fstate = go ? F_RUN : F_OFF;
-    c->step = ST_NONE;
-  }
-}
-
 // ------------------------------------------------------------------ launch wrappers
 
 // tuning knobs of the streamed update (mvx_set_tuning; defaults are the measured best)
@@ -1338,24 +973,6 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
   FB_CASE(4, 1, 0) FB_CASE(4, 0, 0) FB_CASE(4, 1, 1) FB_CASE(4, 0, 1)
 #undef FB_CASE
   std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
-}
-static int host_fs_selectors(int m) {
-  int s = (m + 1 + 127) / 128;
-  return s < 1 ? 1 : (s > FS_MAX_SEL ? FS_MAX_SEL : s);
-}
-void launch_fsboot(Ctl *d_ctl, int m, hipStream_t s) {
-  (void)m;
-  hipLaunchKernelGGL(k_fsboot, dim3(1), dim3(1024), 0, s, d_ctl);
-}
-void launch_fs(Ctl *d_ctl, int m, int n, int par, hipStream_t s) {
-  const long tiles_x = ((n + 2) / 2 + 255) / 256;
-  int tr = ((long)((m + 16) / 16) * tiles_x >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles_x >= 2048) ? 8 : 4;
-  static const int tr_env = getenv("MVX_FS_TR") ? atoi(getenv("MVX_FS_TR")) : 0; // experiment knob
-  if (tr_env == 4 || tr_env == 8 || tr_env == 16) tr = tr_env;
-  const unsigned blocks = (unsigned)host_fs_selectors(m) + (unsigned)(tiles_x * ((m + tr) / tr));
-  if (tr == 16) hipLaunchKernelGGL(k_fs<16>, dim3(blocks), dim3(256), 0, s, d_ctl, par);
-  else if (tr == 8) hipLaunchKernelGGL(k_fs<8>, dim3(blocks), dim3(256), 0, s, d_ctl, par);
-  else hipLaunchKernelGGL(k_fs<4>, dim3(blocks), dim3(256), 0, s, d_ctl, par);
 }
 void launch_select(Ctl *d_ctl, hipStream_t s, int slots) { hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl); }
 void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {

@@ -21,7 +21,6 @@ namespace mvx {
 constexpr int ROWCOMB_CHUNK = 64; // rows per partial sum of k_rowcomb (fixed summation order)
 constexpr int LD_ALIGN = 32;      // doubles; 256-byte rows
 constexpr int ROW_SLACK = 64;     // spare tableau rows per handle for cut appends (cut.cpp:23)
-constexpr int FS_MAX_SEL = 32;    // selector workgroups of the single-launch pipeline (k_fs)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
 
 // state-machine phases (device-driven; mirrors orc_simplex's round loop)
@@ -39,14 +38,6 @@ struct Cand {
   int idx, aux;
 };
 
-// One step of the single-launch primal pipeline (k_fs): chosen by the selector workgroup of launch k,
-// applied by launch k+1.  Two of them ping-pong by launch parity.
-struct FsDesc {
-  int step, p, q, sdir, p_up, leave_flag, tsrc, flipflag;
-  int qn, sdn; // entering column (and direction) of the step AFTER this one, priced ahead; 0 = none
-  double piv, bound, xq, delta;
-  double ent_lb, ent_ub; // bounds of this step's entering variable (= row p's bounds once applied)
-};
 
 // Device-resident control block.  Kernels take only a pointer to it, so one launch
 // sequence (and one captured hipGraph) serves every problem handle.
@@ -79,12 +70,6 @@ struct Ctl {
   int npb, nrb;
   int fstate, curA, curB, flipflag;
   double ent_lb, ent_ub;
-  // single-launch primal pipeline (k_fs): out-of-place update between T and the shadow T2
-  double *T2;       // [(m_cap+1) x ld] shadow tableau (context scratch)
-  double *srow2[2]; // [ld] scaled pivot rows, ping-pong by launch parity
-  unsigned long long *fsp; // [FS_MAX_SEL x 5] ratio-test partials of the selector workgroups (atomics)
-  unsigned int *fscnt;     // arrival counter of the selector workgroups
-  FsDesc fs[2];
 };
 
 // shared immutable matrix row (1-based, n+1 doubles)

@@ -1,6 +1,6 @@
 """GPU busy time per kernel from a rocprofv3 kernel trace (sum of durations, union of intervals)."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv"))[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-28:]) for r in csv.DictReader(open(f))))
 tot = {}
 for s, e, n in rows:

@@ -293,32 +293,25 @@ def test_large_grid_first_pivots_bit_exact(gpu, orc):
         assert np.array_equal(g.tableau(), o.tableau())
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
-def test_both_primal_pipelines_bit_exact(gpu, orc, pipeline):
-    """Primal phase 2 as one launch per pivot (k_fs: out-of-place update + selector workgroup) and as the
-    k_fa / k_fb pair: both against the oracle, including bound flips (boxed columns) and limits that
-    end a batch on either tableau buffer."""
-    try:
-        gpu.use_pipeline(pipeline)
-        A, b, c = synth.dense_lp(150, 420, 31)
-        g, o = gpu.create(), orc.create()
-        for P in (g, o):
-            P.load_dense(A, b, c)
-        for lim in (1, 2, 3, 10, 11):
-            assert g.simplex(it_lim=lim) == o.simplex(it_lim=lim)
-            assert np.array_equal(g.tableau(), o.tableau()), (pipeline, lim)
-        g.simplex()
-        o.simplex()
-        assert_same_state(g, o, "pipeline %d" % pipeline)
-        # boxed columns: primal bound flips inside the pipeline
-        A2, b2, c2, U = synth.dense_ilp(40, 90, 17, 2)
-        g2 = lpgen.load_ilp(gpu, A2, b2, c2, U)
-        o2 = lpgen.load_ilp(orc, A2, b2, c2, U)
-        for P in (g2, o2):
-            P.simplex()
-        assert_same_state(g2, o2, "pipeline %d boxed" % pipeline)
-    finally:
-        gpu.use_pipeline(0)
+def test_fused_primal_path_bit_exact(gpu, orc):
+    """Primal phase 2 on the k_fa / k_fb pair against the oracle: iteration limits that end a batch at
+    every position of the queue, and bound flips of boxed columns inside the fused path."""
+    A, b, c = synth.dense_lp(150, 420, 31)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+    for lim in (1, 2, 3, 10, 11):
+        assert g.simplex(it_lim=lim) == o.simplex(it_lim=lim)
+        assert np.array_equal(g.tableau(), o.tableau()), lim
+    g.simplex()
+    o.simplex()
+    assert_same_state(g, o, "fused")
+    A2, b2, c2, U = synth.dense_ilp(40, 90, 17, 2)
+    g2 = lpgen.load_ilp(gpu, A2, b2, c2, U)
+    o2 = lpgen.load_ilp(orc, A2, b2, c2, U)
+    for P in (g2, o2):
+        P.simplex()
+    assert_same_state(g2, o2, "fused boxed")
 
 
 def test_tall_tableau_dual_path_bit_exact(gpu, orc):
