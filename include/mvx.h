@@ -122,6 +122,14 @@ const char *mvx_get_col_name(const mvx_prob *P, int j);
 int mvx_get_mat_row(const mvx_prob *P, int i, int *ind, double *val);  /* gmi.cpp:84 */
 int mvx_eval_tab_row(const mvx_prob *P, int k, int *ind, double *val); /* gmi.cpp:36 */
 int mvx_get_it_cnt(const mvx_prob *P);
+/* diagnostics of the anti-stalling rules.  After 64 + (m+n)/8 consecutive degenerate pivots, primal
+   phase 2 first perturbs the bounds of the basic variables (once per solve; true bounds return when the
+   phase ends); a second stall, the dual simplex and phase 1 fall back on Bland's smallest-subscript
+   rule until a pivot moves again.  Counts: perturbations applied / pivots chosen by Bland's rule */
+int mvx_get_pert_cnt(const mvx_prob *P);
+/* > 0 overrides the number of consecutive degenerate pivots that arms the rules; 0 = default */
+void mvx_set_stall_limit(int limit);
+int mvx_get_bland_cnt(const mvx_prob *P);
 int mvx_term_out(int flag);      /* glp_term_out 2test.cpp:45,53,62 */
 const char *mvx_version(void);   /* glp_version  util.cpp:278 */
 

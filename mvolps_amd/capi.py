@@ -77,6 +77,9 @@ SIGNATURES = {
     "get_mat_row": (_I, [_P, _I, _IP, _DP]),
     "eval_tab_row": (_I, [_P, _I, _IP, _DP]),
     "get_it_cnt": (_I, [_P]),
+    "get_bland_cnt": (_I, [_P]),
+    "get_pert_cnt": (_I, [_P]),
+    "set_stall_limit": (None, [_I]),
     "term_out": (_I, [_I]),
     "version": (C.c_char_p, []),
     "get_tableau_ld": (_I, [_P]),
@@ -209,6 +212,14 @@ class Prob:
     @property
     def it_cnt(self):
         return self.api.get_it_cnt(self.h)
+
+    @property
+    def bland_cnt(self):
+        return self.api.get_bland_cnt(self.h)
+
+    @property
+    def pert_cnt(self):
+        return self.api.get_pert_cnt(self.h)
 
     def col_prim(self):
         return np.array([self.api.get_col_prim(self.h, j) for j in range(1, self.n + 1)])

@@ -60,6 +60,8 @@ static void reset_model(mvx_prob *P) {
   P->valid = false;
   P->status = MVX_UNDEF;
   P->it_cnt = 0;
+  P->bland_cnt = 0;
+  P->pert_cnt = 0;
   P->last_ms = 0.0;
   P->bvar.clear(); P->nvar.clear(); P->nflag.clear(); P->pos.clear();
   P->sol_fresh = false;
@@ -95,7 +97,7 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   if (names) dst->cname = src->cname; else dst->cname.clear();
   dst->rtype = src->rtype; dst->rlb = src->rlb; dst->rub = src->rub;
   dst->ctype = src->ctype; dst->clb = src->clb; dst->cub = src->cub;
-  dst->status = src->status; dst->it_cnt = src->it_cnt; dst->last_ms = 0.0;
+  dst->status = src->status; dst->it_cnt = src->it_cnt; dst->bland_cnt = src->bland_cnt; dst->pert_cnt = src->pert_cnt; dst->last_ms = 0.0;
   dst->hint_dual = src->hint_dual;
   std::memcpy(dst->last_tol, src->last_tol, sizeof(dst->last_tol));
   dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
@@ -378,6 +380,8 @@ int mvx_eval_tab_row(const mvx_prob *P, int k, int *ind, double *val) {
 }
 
 int mvx_get_it_cnt(const mvx_prob *P) { return P->it_cnt; }
+int mvx_get_bland_cnt(const mvx_prob *P) { return P->bland_cnt; }
+int mvx_get_pert_cnt(const mvx_prob *P) { return P->pert_cnt; }
 int mvx_term_out(int flag) {
   int old = g_term_out;
   g_term_out = flag;
@@ -417,6 +421,7 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
 }
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
 void mvx_use_graphs(int on) { mvx::use_graphs(on); }
+void mvx_set_stall_limit(int limit) { mvx::set_stall_limit(limit); }
 void mvx_set_batch_slots(int slots) { mvx::set_batch_slots(slots); }
 void mvx_profile_enable(int on) { mvx::profile_enable(on); }
 void mvx_profile_reset(void) { mvx::profile_reset(); }

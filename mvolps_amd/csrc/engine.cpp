@@ -59,6 +59,7 @@ struct SolveCtx {
   double *d_colq = nullptr, *d_srow = nullptr, *d_cost1 = nullptr, *d_wts = nullptr, *d_part = nullptr, *d_rcbase = nullptr;
   int *d_gflag = nullptr;
   double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
+  double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
   size_t stage_bytes = 0;
@@ -88,6 +89,7 @@ struct Context {
 };
 
 static Context *g_ctx = nullptr;
+static int g_stall_limit = 0;      // > 0: overrides 64 + (m+n)/8 (tests drive the anti-stalling rules with it)
 static bool g_use_graphs = false; // measured: no gain (dispatch is command-processor-bound, not host-bound)
 static int g_requested_dev = -1;
 
@@ -164,6 +166,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_bc0 = carve((size_t)(mc + 1) * 8), o_bc1 = carve((size_t)(mc + 1) * 8);
   size_t o_pp0 = carve((size_t)fused_npb(l) * sizeof(Cand)), o_pp1 = carve((size_t)fused_npb(l) * sizeof(Cand));
   size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
+  size_t o_olb = carve((size_t)(mc + l + 1) * 8), o_oub = carve((size_t)(mc + l + 1) * 8);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -181,6 +184,8 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_pp[0] = (Cand *)(b + o_pp0);
   sc.d_pp[1] = (Cand *)(b + o_pp1);
   sc.d_rp = (Cand *)(b + o_rp);
+  sc.d_olb = (double *)(b + o_olb);
+  sc.d_oub = (double *)(b + o_oub);
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
@@ -356,6 +361,8 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = 1e-9; h->tol_dj = 1e-9; h->tol_piv = 1e-9;
   h->phase = PH_START; h->done = D_RUN; h->budget = -1;
+  h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
+  h->olb = sc.d_olb; h->oub = sc.d_oub;
   h->colqx[0] = sc.d_colqx[0]; h->colqx[1] = sc.d_colqx[1];
   h->betac[0] = sc.d_betac[0]; h->betac[1] = sc.d_betac[1];
   h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
@@ -505,7 +512,7 @@ struct SolveJob {
   Ctl snap;
 };
 
-// No limit asked for: a safety cap stands in (Dantzig pricing has no anti-cycling rule; a stalled
+// No limit asked for: a safety cap stands in (belt and braces behind the anti-cycling rule; a stalled
 // degenerate LP must end with EITLIM rather than spin on the device).  Same formula as the oracle.
 static int pivot_budget(const mvx_prob *P, const mvx_smcp &parm) {
   return parm.it_lim >= 0 ? parm.it_lim : 200 * (P->m + P->n) + 100000;
@@ -653,6 +660,8 @@ static bool job_finalize(SolveJob &J) {
   HIPCHECK(hipEventElapsedTime(&ms, sc.ev_a, sc.ev_b));
   P->last_ms = ms;
   P->it_cnt += snap.it_cnt;
+  P->bland_cnt += snap.n_bland;
+  P->pert_cnt += snap.n_pert;
   P->hint_dual = false;
   switch (J.done) {
     case D_OPT: P->status = MVX_OPT; J.rc = 0; break;
@@ -706,7 +715,7 @@ static bool job_collect(Context &c, SolveJob &J) {
   }
   J.done = snap.done;
   J.seen_pivots = snap.it_cnt;
-  J.try_fused = (snap.phase == PH_PRIMAL2);
+  J.try_fused = (snap.phase == PH_PRIMAL2) && snap.stall < snap.stall_limit; // the fused path prices by Dantzig only
   if (J.done == D_NEED_PHASE1) {
     snap.done = D_RUN;
     snap.phase = PH_PHASE1;
@@ -807,7 +816,8 @@ static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
   bc.ld = std::max(ld, bc.ld);
   HIPCHECK(hipMalloc((void **)&bc.d_ctl, sizeof(Ctl) * bc.slots));
   HIPCHECK(hipHostMalloc((void **)&bc.h_ctl, sizeof(Ctl) * bc.slots));
-  bc.scratch_stride = align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256);
+  bc.scratch_stride = align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256) +
+                      2 * align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256);
   HIPCHECK(hipMalloc((void **)&bc.scratch, bc.scratch_stride * bc.slots));
   HIPCHECK(hipMemsetAsync(bc.scratch, 0, bc.scratch_stride * bc.slots, bc.stream));
   bc.stage_stride = stage_size(bc.m_cap, bc.ld);
@@ -828,10 +838,13 @@ static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &pa
   h->nvar = P->d_nvar; h->nflag = P->d_nflag; h->nlb = P->d_nlb; h->nub = P->d_nub;
   h->colq = (double *)sb;
   h->srow = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256));
+  h->olb = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256));
+  h->oub = h->olb + align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) / 8;
   h->m = P->m; h->n = P->n; h->ld = P->ld; h->m_cap = P->m_cap;
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = parm.tol_bnd; h->tol_dj = parm.tol_dj; h->tol_piv = parm.tol_piv;
   h->phase = PH_START; h->done = D_RUN; h->budget = pivot_budget(P, parm);
+  h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->fstate = F_OFF;
   HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], h, sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
 }
@@ -855,6 +868,8 @@ static int batch_finish_slot(BatchCtx &bc, int k, mvx_prob *P) {
   P->sol_fresh = true;
   P->last_ms = 0.0;
   P->it_cnt += snap.it_cnt;
+  P->bland_cnt += snap.n_bland;
+  P->pert_cnt += snap.n_pert;
   P->hint_dual = false;
   switch (snap.done) {
     case D_OPT: P->status = MVX_OPT; return 0;
@@ -933,6 +948,8 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
       if (snap.done == D_NEED_PHASE1) {
         fallback.push_back(i); // neither primal nor dual feasible: finish on the single-handle path
         probs[i]->it_cnt += snap.it_cnt;
+        probs[i]->bland_cnt += snap.n_bland;
+        probs[i]->pert_cnt += snap.n_pert;
       } else {
         const int rc = batch_finish_slot(bc, k, probs[i]);
         if (rcs) rcs[i] = rc;
@@ -1253,6 +1270,7 @@ void tuning(int tr, int hot, int nt) {
 }
 
 void use_graphs(int on) { g_use_graphs = on != 0; }
+void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }
 void profile_enable(int on) { ctx().prof = on != 0; }
 void profile_reset() {

@@ -79,9 +79,12 @@ __device__ Cand block_best(Cand c, Cand *lds) {
 // every helper.
 struct KC {
   double *T;
-  const double *blb, *bub, *nlb, *nub;
+  double *blb, *bub, *nlb, *nub;
   int *nflag;
   double *colq, *srow;
+  int *bvar, *nvar;
+  double *olb, *oub;
+  int bland; // Bland's rule in force (stall >= stall_limit)
   int m, n, ld;
   double tol_bnd, tol_dj, tol_piv, sgn;
 };
@@ -91,6 +94,9 @@ __device__ __forceinline__ KC load_kc(const Ctl *c) {
   k.blb = c->blb; k.bub = c->bub; k.nlb = c->nlb; k.nub = c->nub;
   k.nflag = c->nflag;
   k.colq = c->colq; k.srow = c->srow;
+  k.bvar = c->bvar; k.nvar = c->nvar;
+  k.olb = c->olb; k.oub = c->oub;
+  k.bland = c->stall >= c->stall_limit;
   k.m = c->m; k.n = c->n; k.ld = c->ld;
   k.tol_bnd = c->tol_bnd; k.tol_dj = c->tol_dj; k.tol_piv = c->tol_piv; k.sgn = c->sgn;
   return k;
@@ -111,7 +117,7 @@ __device__ Cand dev_infeas_row(const KC &k, Cand *lds) {
       up = 1;
     }
     if (viol > 0.0) {
-      Cand x{viol, 0.0, i, up};
+      Cand x{k.bland ? -(double)k.bvar[i] : viol, 0.0, i, up}; // Bland: lowest variable number wins
       if (cand_better<0>(x, best)) best = x;
     }
   }
@@ -128,7 +134,7 @@ __device__ Cand dev_price(const KC &k, const double *cost, double sgn, Cand *lds
     const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
     const bool dn = (f == MVX_NU || f == MVX_NF) && dj < -tol;
     if (!up && !dn) continue;
-    Cand x{fabs(dj), 0.0, j, up ? 1 : -1};
+    Cand x{k.bland ? -(double)k.nvar[j] : fabs(dj), 0.0, j, up ? 1 : -1};
     if (cand_better<0>(x, best)) best = x;
   }
   return block_best<0>(best, lds);
@@ -179,7 +185,10 @@ __device__ Cand dev_primal_ratio(const KC &k, int q, int sdir, const int *g, Can
     k.colq[i] = a;
     if (i == 0) continue;
     Cand x;
-    if (ratio_row(a, sdir, k.T[(size_t)i * ld], k.blb[i], k.bub[i], g ? g[i] : 0, tp, i, x) && cand_better<1>(x, best)) best = x;
+    if (ratio_row(a, sdir, k.T[(size_t)i * ld], k.blb[i], k.bub[i], g ? g[i] : 0, tp, i, x)) {
+      if (k.bland) x.k2 = -(double)k.bvar[i]; // tie-break among equal steps
+      if (cand_better<1>(x, best)) best = x;
+    }
   }
   return block_best<1>(best, lds);
 }
@@ -205,7 +214,7 @@ __device__ Cand dev_dual_ratio(const KC &k, int p, int to_upper, Cand *lds) {
       continue;
     const double mag = fabs(a);
     r = r / mag;
-    Cand x{r, mag, j, 0};
+    Cand x{r, k.bland ? -(double)k.nvar[j] : mag, j, 0};
     if (cand_better<1>(x, best)) best = x;
   }
   return block_best<1>(best, lds);
@@ -258,13 +267,98 @@ __device__ bool dev_primal_step(const KC &k, Ctl *c, int q, int sdir, const int 
         k.nflag[q] = (sdir > 0) ? MVX_NU : MVX_NL;
         c->step = ST_FLIP;
         c->n_flips++;
+        c->stall = 0;
       }
       return true;
     }
   }
   if (r.idx == 0) return false;
   dev_prepare_pivot(k, c, r.idx, q, r.aux);
+  if (TIDX == 0) {
+    if (k.bland) c->n_bland++;
+    c->stall = (r.k1 <= DEGEN_TOL) ? c->stall + 1 : 0;
+  }
   return true;
+}
+
+// splitmix64 of the variable number -> [0,1) (oracle: pert_unit)
+__device__ __forceinline__ double dev_pert_unit(int var) {
+  unsigned long long z = (unsigned long long)var * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// Anti-stalling perturbation (oracle: perturb_basis): save every variable's bounds by variable number,
+// then push the bounds of the basic variables outwards by tiny distinct amounts.  All threads call.
+__device__ void dev_perturb(const KC &k, Ctl *c) {
+  const int bs = (int)blockDim.x;
+  for (int j = 1 + TIDX; j <= k.n; j += bs) {
+    const int var = k.nvar[j];
+    k.olb[var] = k.nlb[j];
+    k.oub[var] = k.nub[j];
+  }
+  for (int i = 1 + TIDX; i <= k.m; i += bs) {
+    const int var = k.bvar[i];
+    const double lb = k.blb[i], ub = k.bub[i];
+    k.olb[var] = lb;
+    k.oub[var] = ub;
+    const double u = 1.0 + dev_pert_unit(var);
+    if (lb > -INFINITY) {
+      double d = PERT_EPS * (1.0 + fabs(lb));
+      d = d * u;
+      k.blb[i] = lb - d;
+    }
+    if (ub < INFINITY) {
+      double d = PERT_EPS * (1.0 + fabs(ub));
+      d = d * u;
+      k.bub[i] = ub + d;
+    }
+  }
+  if (TIDX == 0) {
+    c->perturbed = 1;
+    c->pert_used = 1;
+    c->n_pert++;
+    c->stall = 0;
+  }
+}
+
+// True bounds back on every position (oracle: restore_bounds); non-basic variables parked on a
+// perturbed bound move to the true one: column 0 takes the shifts column by column in ascending
+// order, each row its own fma chain -- the order shift_nonbasic is applied in by the oracle.
+__device__ void dev_restore(const KC &k, Ctl *c) {
+  const int bs = (int)blockDim.x;
+  const size_t ld = (size_t)k.ld;
+  for (int i = 1 + TIDX; i <= k.m; i += bs) {
+    const int var = k.bvar[i];
+    k.blb[i] = k.olb[var];
+    k.bub[i] = k.oub[var];
+  }
+  for (int j = 1 + TIDX; j <= k.n; j += bs) {
+    const int var = k.nvar[j];
+    const double lb = k.olb[var], ub = k.oub[var];
+    int f = k.nflag[j];
+    const double xold = dev_nb_value(f, k.nlb[j], k.nub[j]);
+    if (lb == ub) f = MVX_NS;
+    k.nlb[j] = lb;
+    k.nub[j] = ub;
+    k.nflag[j] = f;
+    const double xnew = dev_nb_value(f, lb, ub);
+    k.srow[j] = (xnew != xold) ? xnew - xold : 0.0; // srow is free between pivots
+  }
+  __syncthreads();
+  for (int i = TIDX; i <= k.m; i += bs) {
+    const double *row = k.T + (size_t)i * ld;
+    double beta = row[0];
+    for (int j = 1; j <= k.n; j++) {
+      const double d = k.srow[j];
+      if (d != 0.0) beta = fma(row[j], d, beta);
+    }
+    k.T[(size_t)i * ld] = beta;
+  }
+  __syncthreads();
+  if (TIDX == 0) c->perturbed = 0;
 }
 
 __device__ __forceinline__ void dev_finish(Ctl *c, int code, int phase, int rounds) {
@@ -304,12 +398,33 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
       }
     }
     if (phase == PH_PRIMAL2) {
+      if (k.bland && !c->pert_used) {
+        // stalled for the first time: perturb instead of pivoting; the next launch prices again
+        dev_perturb(k, c);
+        if (TIDX == 0) {
+          c->step = ST_NONE;
+          c->phase = phase;
+          c->rounds = rounds;
+        }
+        return;
+      }
       Cand pr = dev_price(k, k.T, k.sgn, lds);
       if (pr.idx != 0) {
         q = pr.idx;
         sdir = pr.aux;
         kind = 1;
         break;
+      }
+      if (c->perturbed) {
+        // optimal for the perturbed bounds: true bounds back, then look again (the dual simplex
+        // removes what infeasibility the shift leaves)
+        dev_restore(k, c);
+        if (TIDX == 0) {
+          c->step = ST_NONE;
+          c->phase = phase;
+          c->rounds = rounds;
+        }
+        return;
       }
       Cand r = dev_infeas_row(k, lds);
       if (r.idx == 0) {
@@ -342,11 +457,13 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
     }
   }
   if (c->budget == 0) {
+    if (c->perturbed) dev_restore(k, c);
     dev_finish(c, D_ITLIM, phase, rounds);
     return;
   }
   if (kind == 1) {
     if (!dev_primal_step(k, c, q, sdir, nullptr, lds)) {
+      if (c->perturbed) dev_restore(k, c);
       dev_finish(c, D_UNBND, phase, rounds);
       return;
     }
@@ -360,6 +477,10 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
     const size_t ld = (size_t)k.ld;
     for (int i = TIDX; i <= k.m; i += (int)blockDim.x) k.colq[i] = k.T[(size_t)i * ld + q];
     dev_prepare_pivot(k, c, p, q, p_up);
+    if (TIDX == 0) {
+      if (k.bland) c->n_bland++;
+      c->stall = (dr.k1 <= DEGEN_TOL) ? c->stall + 1 : 0;
+    }
   }
   if (TIDX == 0) {
     c->phase = phase;
@@ -603,7 +724,7 @@ __device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, C
 // bootstrap: price the current objective row into pp[0]; arm the fused path
 __global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
   __shared__ Cand lds[17];
-  if (c->done != D_RUN || c->phase != PH_PRIMAL2) {
+  if (c->done != D_RUN || c->phase != PH_PRIMAL2 || c->stall >= c->stall_limit) { // fused path prices by Dantzig only
     if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
     return;
   }
@@ -641,6 +762,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
   __shared__ Cand lds[17];
   // level 1
   const int done = c->done, fstate = c->fstate, cur = c->curA, budget = c->budget;
+  const int stall = c->stall, stall_limit = c->stall_limit;
   const int npb = c->npb, nrb = c->nrb, n = c->n, ldi = c->ld;
   double *const T = c->T;
   double *const srow = c->srow;
@@ -680,8 +802,9 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
     }
     pc = wave_bcast_best<0>(pc);
     rc = wave_bcast_best<1>(rc);
-    // entering column
-    if (pc.idx == 0 || budget == 0) {
+    // entering column (none, no budget, or a stalled run that Bland's rule must take over: the generic
+    // path continues)
+    if (pc.idx == 0 || budget == 0 || stall >= stall_limit) {
       if (lead) c->fstate = F_STOP;
       return;
     }
@@ -713,6 +836,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
           c->delta = (sdir > 0) ? tf : -tf;
           c->flipflag = nf;
           c->curB = cur;
+          c->stall_new = 0;
         }
         return;
       }
@@ -748,6 +872,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
       c->ent_lb = lbq;
       c->ent_ub = ubq;
       c->curB = cur;
+      c->stall_new = (rc.k1 <= DEGEN_TOL) ? stall + 1 : 0;
     }
   }
 }
@@ -932,9 +1057,11 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
       c->nflag[q] = c->leave_flag;
       c->it_cnt++;
       if (c->budget > 0) c->budget--;
+      c->stall = c->stall_new;
     } else if (step == ST_FLIP) {
       c->nflag[q] = c->flipflag;
       c->n_flips++;
+      c->stall = c->stall_new;
     }
     c->curA = nxt;
     c->nrb = (int)gridDim.y; // number of ratio-test partials this launch leaves for k_fa

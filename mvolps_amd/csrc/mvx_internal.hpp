@@ -21,6 +21,8 @@ namespace mvx {
 constexpr int ROWCOMB_CHUNK = 64; // rows per partial sum of k_rowcomb (fixed summation order)
 constexpr int LD_ALIGN = 32;      // doubles; 256-byte rows
 constexpr int ROW_SLACK = 64;     // spare tableau rows per handle for cut appends (cut.cpp:23)
+constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this counts as degenerate (oracle: DEGEN_TOL)
+constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
 
 // state-machine phases (device-driven; mirrors orc_simplex's round loop)
@@ -59,7 +61,7 @@ struct Ctl {
   double sgn, tol_bnd, tol_dj, tol_piv;
   // running state
   int phase, done, rounds, budget;
-  int it_cnt, n_flips;
+  int it_cnt, n_flips, n_bland;
   int step, p, q, sdir, p_up, leave_flag;
   double piv, bound, xq, delta;
   // fused primal fast path (k_fboot / k_fa / k_fb): ping-pong buffers indexed by parity
@@ -69,6 +71,14 @@ struct Ctl {
   Cand *rp;         // [nrb] ratio-test partials (one per k_fb row block)
   int npb, nrb;
   int fstate, curA, curB, flipflag;
+  // anti-cycling (oracle: ctl_t.stall): consecutive degenerate pivots; from stall_limit on every choice
+  // follows Bland's smallest-subscript rule until a pivot moves again
+  int stall, stall_limit;
+  // bound perturbation against stalling (oracle: perturb_basis / restore_bounds): original bounds by
+  // variable number, saved when the perturbation is applied
+  double *olb, *oub;
+  int perturbed, pert_used, n_pert;
+  int stall_new; // fused path: k_fa's verdict on the step it prepared, committed by k_fb (k_fa workgroups read `stall`)
   double ent_lb, ent_ub;
 };
 
@@ -93,6 +103,8 @@ struct mvx_prob {
   bool valid = false;   // device tableau + basis exist
   int status = MVX_UNDEF;
   int it_cnt = 0;
+  int pert_cnt = 0;  // bound perturbations applied against stalling, diagnostic
+  int bland_cnt = 0; // pivots chosen under the anti-cycling (Bland) rule, diagnostic
   double last_ms = 0.0;
   double last_tol[3] = {0.0, 0.0, 0.0}; // tolerances of the solve that produced `status`
   bool hint_dual = false; // last edit made a basic variable infeasible: start in the dual simplex

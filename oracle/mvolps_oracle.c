@@ -44,9 +44,13 @@ struct orc_prob {
   double *nlb, *nub;
   int status;
   int it_cnt;
+  int bland_cnt; /* pivots chosen by Bland's rule (diagnostic) */
+  int pert_cnt;  /* bound perturbations applied (diagnostic) */
 };
 
 static int g_term_out = 1;
+static int g_stall_limit = 0; /* > 0: overrides 64 + (m+n)/8 (tests drive the anti-stalling rules with it) */
+void orc_set_stall_limit(int limit) { g_stall_limit = limit; }
 
 /* ------------------------------------------------------------------ helpers */
 static void *xcalloc(size_t n, size_t sz) {
@@ -213,6 +217,8 @@ void orc_copy_prob(orc_prob *dst, const orc_prob *src, int names) {
   dst->valid = src->valid;
   dst->status = src->status;
   dst->it_cnt = src->it_cnt;
+  dst->bland_cnt = src->bland_cnt;
+  dst->pert_cnt = src->pert_cnt;
   if (src->valid) {
     dst->ld = src->ld;
     dst->T = (double *)xcalloc((size_t)(dst->m_cap + 1) * dst->ld, sizeof(double));
@@ -512,11 +518,27 @@ int orc_load_dense(orc_prob *P, int m, int n, const double *A, const double *b, 
 typedef struct {
   double tol_bnd, tol_dj, tol_piv;
   int budget; /* remaining pivots, <0 = unlimited */
+  /* anti-cycling: `stall` counts consecutive degenerate pivots (step length at most DEGEN_TOL).  From
+     `stall_limit` on, every choice is made by Bland's smallest-subscript rule (entering and leaving
+     variable by lowest variable number) until a pivot moves again; a cycle consists of degenerate
+     pivots only, so this ends it.  The HIP engine keeps the same two counters in its control block. */
+  int stall, stall_limit;
+  /* first line of defence against stalling, primal phase 2 only: when `stall` first reaches the limit
+     the bounds of all basic variables are pushed outwards by tiny, distinct amounts (PERT_EPS), which
+     breaks the ties of a degenerate vertex; the true bounds come back when phase 2 ends (the dual
+     simplex then removes what infeasibility is left).  Used once per solve; Bland's rule covers a
+     second stall, the dual simplex and phase 1. */
+  int perturbed, pert_used;
 } ctl_t;
+
+#define PERT_EPS 1e-6
+#define DEGEN_TOL 1e-9 /* a step (primal) or dual ratio no longer than this counts as degenerate */
+
+static int bland_on(const ctl_t *ctl) { return ctl->stall >= ctl->stall_limit; }
 
 /* Dantzig pricing on row `cost` (length n+1, entries 1..n), maximisation sense already
    folded in through sgn.  Returns column q (0 = none), *sdir = +1 (increase) / -1. */
-static int price(const orc_prob *P, const double *cost, double sgn, double tol, int *sdir) {
+static int price(const orc_prob *P, const double *cost, double sgn, double tol, int *sdir, int bland) {
   int q = 0;
   double best = 0.0;
   for (int j = 1; j <= P->n; j++) {
@@ -526,7 +548,7 @@ static int price(const orc_prob *P, const double *cost, double sgn, double tol, 
     int up = (f == ORC_NL || f == ORC_NF) && dj > tol;
     int dn = (f == ORC_NU || f == ORC_NF) && dj < -tol;
     if (!up && !dn) continue;
-    double sc = fabs(dj);
+    double sc = bland ? -(double)P->nvar[j] : fabs(dj); /* Bland: lowest variable number wins */
     if (q == 0 || sc > best) { /* strict > keeps the lowest j on ties */
       best = sc;
       q = j;
@@ -547,7 +569,7 @@ static int better(double t, double mag, int idx, double bt, double bmag, int bid
 }
 
 /* row of maximal primal infeasibility (0 = feasible); *to_upper = 1 if above ub */
-static int select_infeasible_row(const orc_prob *P, double tol_bnd, int *to_upper) {
+static int select_infeasible_row(const orc_prob *P, double tol_bnd, int *to_upper, int bland) {
   int p = 0;
   double best = 0.0;
   for (int i = 1; i <= P->m; i++) {
@@ -560,8 +582,9 @@ static int select_infeasible_row(const orc_prob *P, double tol_bnd, int *to_uppe
       viol = beta - ub;
       up = 1;
     }
-    if (viol > 0.0 && (p == 0 || viol > best)) {
-      best = viol;
+    double sc = bland ? -(double)P->bvar[i] : viol;
+    if (viol > 0.0 && (p == 0 || sc > best)) {
+      best = sc;
       p = i;
       *to_upper = up;
     }
@@ -618,6 +641,7 @@ enum { R_OPT = 1, R_UNBND, R_NOFEAS, R_ITLIM, R_PFEAS, R_FAIL };
 static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
   int m = P->m;
   int p = 0, p_up = 0;
+  const int bland = bland_on(ctl);
   double bt = 0.0, bmag = 0.0;
   for (int i = 1; i <= m; i++) {
     double a = TT(P, i, q);
@@ -644,7 +668,7 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
     } else
       continue;
     if (t < 0.0) t = 0.0;
-    double mag = fabs(a);
+    double mag = bland ? -(double)P->bvar[i] : fabs(a); /* tie-break among equal steps */
     if (better(t, mag, i, bt, bmag, p)) {
       bt = t;
       bmag = mag;
@@ -659,6 +683,7 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
       double delta = (sdir > 0) ? tf : -tf;
       shift_nonbasic(P, q, delta);
       P->nflag[q] = (sdir > 0) ? ORC_NU : ORC_NL;
+      ctl->stall = 0;
       return 0;
     }
   }
@@ -666,18 +691,78 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
   double bound = p_up ? P->bub[p] : P->blb[p];
   pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], p_up));
   if (ctl->budget > 0) ctl->budget--;
+  if (bland) P->bland_cnt++;
+  ctl->stall = (bt <= DEGEN_TOL) ? ctl->stall + 1 : 0;
   return 0;
+}
+
+/* splitmix64 of the variable number -> [0,1): the same amount for a variable wherever it sits */
+static double pert_unit(int var) {
+  unsigned long long z = (unsigned long long)var * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+static void var_true_bounds(const orc_prob *P, int k, double *lb, double *ub) {
+  if (k <= P->m) { *lb = P->rlb[k]; *ub = P->rub[k]; }
+  else { *lb = P->clb[k - P->m]; *ub = P->cub[k - P->m]; }
+}
+
+static void perturb_basis(orc_prob *P, ctl_t *ctl) {
+  for (int i = 1; i <= P->m; i++) {
+    double u = 1.0 + pert_unit(P->bvar[i]);
+    if (P->blb[i] > -INF) {
+      double d = PERT_EPS * (1.0 + fabs(P->blb[i]));
+      d = d * u;
+      P->blb[i] = P->blb[i] - d;
+    }
+    if (P->bub[i] < INF) {
+      double d = PERT_EPS * (1.0 + fabs(P->bub[i]));
+      d = d * u;
+      P->bub[i] = P->bub[i] + d;
+    }
+  }
+  ctl->perturbed = 1;
+  ctl->pert_used = 1;
+  ctl->stall = 0;
+  P->pert_cnt++;
+}
+
+/* true bounds back on every position; non-basic variables parked on a perturbed bound move to the true
+   one (columns in ascending order, one shift_nonbasic each) */
+static void restore_bounds(orc_prob *P, ctl_t *ctl) {
+  for (int i = 1; i <= P->m; i++) var_true_bounds(P, P->bvar[i], &P->blb[i], &P->bub[i]);
+  for (int j = 1; j <= P->n; j++) {
+    double lb, ub;
+    var_true_bounds(P, P->nvar[j], &lb, &ub);
+    int f = P->nflag[j];
+    double xold = nb_value(f, P->nlb[j], P->nub[j]);
+    if (lb == ub) f = ORC_NS;
+    P->nlb[j] = lb;
+    P->nub[j] = ub;
+    P->nflag[j] = f;
+    double xnew = nb_value(f, lb, ub);
+    if (xnew != xold) shift_nonbasic(P, j, xnew - xold);
+  }
+  ctl->perturbed = 0;
 }
 
 static int primal_phase2(orc_prob *P, ctl_t *ctl) {
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
   for (;;) {
     int sdir = 0;
-    int q = price(P, &TT(P, 0, 0), sgn, ctl->tol_dj, &sdir);
-    if (q == 0) return R_OPT;
-    if (ctl->budget == 0) return R_ITLIM;
-    int r = primal_step(P, ctl, q, sdir, NULL);
-    if (r) return r;
+    if (bland_on(ctl) && !ctl->pert_used) perturb_basis(P, ctl);
+    int q = price(P, &TT(P, 0, 0), sgn, ctl->tol_dj, &sdir, bland_on(ctl));
+    int r = 0;
+    if (q == 0) r = R_OPT;
+    else if (ctl->budget == 0) r = R_ITLIM;
+    else r = primal_step(P, ctl, q, sdir, NULL);
+    if (r) {
+      if (ctl->perturbed) restore_bounds(P, ctl);
+      return r;
+    }
   }
 }
 
@@ -700,7 +785,7 @@ static int primal_phase1(orc_prob *P, ctl_t *ctl) {
     if (ninf == 0) { ret = R_PFEAS; break; }
     rowcomb(P, w, NULL, cost);
     int sdir = 0;
-    int q = price(P, cost, 1.0, ctl->tol_dj, &sdir);
+    int q = price(P, cost, 1.0, ctl->tol_dj, &sdir, bland_on(ctl));
     if (q == 0) { ret = R_NOFEAS; break; }
     if (ctl->budget == 0) { ret = R_ITLIM; break; }
     int r = primal_step(P, ctl, q, sdir, g);
@@ -715,7 +800,8 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
   for (;;) {
     int to_upper = 0;
-    int p = select_infeasible_row(P, ctl->tol_bnd, &to_upper);
+    const int bland = bland_on(ctl);
+    int p = select_infeasible_row(P, ctl->tol_bnd, &to_upper, bland);
     if (p == 0) return R_PFEAS;
     if (ctl->budget == 0) return R_ITLIM;
     int need_inc = !to_upper; /* below lb: the basic variable must increase */
@@ -736,6 +822,7 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
         continue;
       double mag = fabs(a);
       r = r / mag;
+      if (bland) mag = -(double)P->nvar[j]; /* tie-break among equal ratios */
       if (better(r, mag, j, br, bmag, q)) {
         br = r;
         bmag = mag;
@@ -746,6 +833,8 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
     double bound = to_upper ? P->bub[p] : P->blb[p];
     pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], to_upper));
     if (ctl->budget > 0) ctl->budget--;
+    if (bland) P->bland_cnt++;
+    ctl->stall = (br <= DEGEN_TOL) ? ctl->stall + 1 : 0;
   }
 }
 
@@ -769,19 +858,20 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
     return ORC_EFAIL;
   }
   if (!P->valid) build_slack_tableau(P);
-  /* no limit asked for: a safety cap stands in (Dantzig pricing has no anti-cycling rule; a stalled
-     degenerate LP must end with EITLIM rather than spin).  Same formula in the HIP engine. */
+  /* no limit asked for: a safety cap stands in (belt and braces behind the anti-cycling rule: a solve
+     must end with EITLIM rather than spin).  Same formula in the HIP engine. */
   int budget = parm->it_lim >= 0 ? parm->it_lim : 200 * (P->m + P->n) + 100000;
-  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, budget};
+  int stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
+  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, budget, 0, stall_limit, 0, 0};
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
   for (int round = 0; round < 64; round++) {
     int to_upper = 0, sdir = 0;
-    int p = select_infeasible_row(P, ctl.tol_bnd, &to_upper);
+    int p = select_infeasible_row(P, ctl.tol_bnd, &to_upper, 0); /* existence only */
     int r;
     if (p == 0) {
       r = primal_phase2(P, &ctl);
       if (r == R_OPT) {
-        if (select_infeasible_row(P, ctl.tol_bnd, &to_upper) == 0) {
+        if (select_infeasible_row(P, ctl.tol_bnd, &to_upper, 0) == 0) {
           P->status = ORC_OPT;
           return 0;
         }
@@ -791,7 +881,7 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
       P->status = ORC_FEAS;
       return ORC_EITLIM;
     }
-    int q = (parm->meth == 2) ? 1 : price(P, &TT(P, 0, 0), sgn, ctl.tol_dj, &sdir);
+    int q = (parm->meth == 2) ? 1 : price(P, &TT(P, 0, 0), sgn, ctl.tol_dj, &sdir, 0); /* existence only */
     r = (q == 0) ? dual_simplex(P, &ctl) : primal_phase1(P, &ctl);
     if (r == R_PFEAS) continue;
     if (r == R_NOFEAS) { P->status = ORC_NOFEAS; return 0; }
@@ -938,6 +1028,8 @@ int orc_eval_tab_row(const orc_prob *P, int k, int *ind, double *val) {
 }
 
 int orc_get_it_cnt(const orc_prob *P) { return P->it_cnt; }
+int orc_get_bland_cnt(const orc_prob *P) { return P->bland_cnt; }
+int orc_get_pert_cnt(const orc_prob *P) { return P->pert_cnt; }
 int orc_term_out(int flag) {
   int old = g_term_out;
   g_term_out = flag;

@@ -119,6 +119,9 @@ const char *orc_get_col_name(const orc_prob *P, int j);
 int orc_get_mat_row(const orc_prob *P, int i, int *ind, double *val);
 int orc_eval_tab_row(const orc_prob *P, int k, int *ind, double *val);
 int orc_get_it_cnt(const orc_prob *P);
+int orc_get_bland_cnt(const orc_prob *P); /* pivots chosen under the anti-cycling (Bland) rule */
+void orc_set_stall_limit(int limit); /* > 0 overrides the 64 + (m+n)/8 degenerate pivots that arm the rules; 0 = default */
+int orc_get_pert_cnt(const orc_prob *P);  /* bound perturbations applied against stalling */
 int orc_term_out(int flag);
 const char *orc_version(void);
 

@@ -47,6 +47,33 @@ for k in range(120):
     if not same(g, o):
         bad.append(("dense", k, m, n))
 print("dense done", time.time() - t0, "bad", len(bad), flush=True)
+n_pert = n_bland = 0
+for k in range(60):
+    m, n = int(rng.integers(20, 260)), int(rng.integers(20, 320))
+    A, b, c = lpgen.degenerate_lp(m, n, 9000 + k, frac0=float(rng.choice([0.5, 0.8, 0.95, 1.0])))
+    g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+    lim = int(rng.integers(20, 400))
+    for P in (g, o):
+        P.simplex(it_lim=lim)
+    if not same(g, o):
+        bad.append(("degenerate-limit", k, m, n))
+    for P in (g, o):
+        P.simplex()
+    if not same(g, o) or g.pert_cnt != o.pert_cnt or g.bland_cnt != o.bland_cnt:
+        bad.append(("degenerate", k, m, n))
+    n_pert += o.pert_cnt
+    n_bland += o.bland_cnt
+    x = o.col_prim()
+    frac = [j + 1 for j in range(len(x)) if np.trunc(x[j]) != x[j]]
+    for j in frac[:2]:
+        for P in (g, o):
+            P.kid = P.copy()
+            P.api.set_col_bnds(P.kid.h, j, capi.UP, 0.0, float(np.floor(x[j - 1])))
+            P.kid.simplex()
+        if not same(g.kid, o.kid):
+            bad.append(("degenerate-child", k, j))
+        n_bland += o.kid.bland_cnt
+print("degenerate done", time.time() - t0, "bad", len(bad), "perturbations", n_pert, "bland pivots", n_bland, flush=True)
 for k in range(40):
     m, n = int(rng.integers(4, 20)), int(rng.integers(6, 36))
     A, b, c, U = synth.dense_ilp(m, n, 7000 + k, int(rng.integers(1, 4)))

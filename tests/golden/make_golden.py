@@ -85,6 +85,22 @@ def ilp_cases():
     return out
 
 
+def degenerate_cases():
+    """Stalling / cycling LPs: the anti-stalling rules (bound perturbation, Bland fallback) must still land on
+    the optimum HiGHS finds."""
+    out = []
+    for name, (A, b, c) in lpgen.CYCLING.items():
+        r = linprog(-np.array(c), A_ub=np.array(A), b_ub=np.array(b), bounds=(0, None), method="highs-ds")
+        assert r.status == 0
+        out.append({"name": name, "obj": float(-r.fun)})
+    for (m, n, seed) in [(30, 40, 1), (100, 150, 3), (300, 120, 6), (150, 150, 7), (200, 300, 4), (250, 400, 8)]:
+        A, b, c = lpgen.degenerate_lp(m, n, seed)
+        r = linprog(-c, A_ub=A, b_ub=b, bounds=(0, 2), method="highs-ds")
+        assert r.status == 0
+        out.append({"m": m, "n": n, "seed": seed, "obj": float(-r.fun)})
+    return out
+
+
 def main():
     big = "--big" in sys.argv
     doc = {
@@ -93,10 +109,12 @@ def main():
         "dense": dense_cases(big),
         "general": general_cases(),
         "ilp": ilp_cases(),
+        "degenerate": degenerate_cases(),
     }
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(doc, f, indent=1)
-    print("wrote golden.json: %d dense, %d general, %d ilp" % (len(doc["dense"]), len(doc["general"]), len(doc["ilp"])))
+    print("wrote golden.json: %d dense, %d general, %d ilp, %d degenerate" % (len(doc["dense"]), len(doc["general"]), len(doc["ilp"]),
+                                                                            len(doc["degenerate"])))
 
 
 if __name__ == "__main__":

@@ -50,3 +50,27 @@ def load_ilp(api, A, b, c, U):
     colb = [(DB, 0.0, U) if np.isfinite(U) else (LO, 0.0, 0.0)] * n
     P.load_general(A, [(UP, 0.0, float(bi)) for bi in b], colb, c, kinds=[IV] * n, direction=MAX)
     return P
+
+
+def degenerate_lp(m, n, seed, frac0=0.9):
+    """max c x, A x <= b, 0 <= x <= 2, integer data, about 90 % of b equal to zero: the slack basis is a
+    massively degenerate vertex on which plain Dantzig pricing stalls (200x300 seed 4 never leaves it)."""
+    rng = np.random.default_rng(seed)
+    A = rng.integers(-3, 4, size=(m, n)).astype(float)
+    b = np.where(rng.random(m) < frac0, 0.0, rng.integers(1, 5, size=m).astype(float))
+    c = rng.integers(1, 6, size=n).astype(float)
+    return A, b, c
+
+
+def load_degenerate(api, A, b, c):
+    from mvolps_amd.capi import DB, UP
+    P = api.create()
+    P.load_general(A, [(UP, 0.0, float(x)) for x in b], [(DB, 0.0, 2.0)] * A.shape[1], c)
+    return P
+
+
+# textbook LPs on which Dantzig pricing with lowest-index ties cycles (max c x, A x <= b, x >= 0)
+CYCLING = {
+    "beale": ([[0.25, -8, -1, 9], [0.5, -12, -0.5, 3], [0, 0, 1, 0]], [0, 0, 1.0], [0.75, -20, 0.5, -6]),
+    "chvatal": ([[0.5, -5.5, -2.5, 9], [0.5, -1.5, -0.5, 1], [1, 0, 0, 0]], [0, 0, 1.0], [10, -57, -9, -24.0]),
+}

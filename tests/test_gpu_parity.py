@@ -357,3 +357,78 @@ def test_tall_tableau_dual_path_bit_exact(gpu, orc):
             P.api.set_col_bnds(P.h, j, LO, float(np.ceil(xg[j - 1])), 0.0)
             P.simplex()
         assert_same_state(kids_g[0], kids_o[0], "tall grandchild")
+
+
+def test_stalling_lps_bit_exact(gpu, orc):
+    """The anti-stalling rules on the device against the oracle: textbook cycling LPs, a massively degenerate
+    LP that needs the bound perturbation (applied by k_select, removed when phase 2 ends, cleaned up by the
+    dual simplex), the same LP cut short by an iteration limit while perturbed, and Bland's rule forced on
+    from the first degenerate pivot of a warm-started dual solve."""
+    for name, (A, b, c) in lpgen.CYCLING.items():
+        A, b, c = (np.array(v, float) for v in (A, b, c))
+        g, o = gpu.create(), orc.create()
+        for P in (g, o):
+            P.load_dense(A, b, c)
+            assert P.simplex() == 0
+        assert g.pert_cnt == o.pert_cnt and g.bland_cnt == o.bland_cnt
+        assert_same_state(g, o, name)
+    A, b, c = lpgen.degenerate_lp(150, 150, 7)
+    g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+    for P in (g, o):
+        assert P.simplex() == 0
+    assert g.pert_cnt == o.pert_cnt == 1
+    assert g.bland_cnt == o.bland_cnt
+    assert_same_state(g, o, "degenerate 150x150")
+    # an iteration limit that falls inside the perturbed stretch: bounds are restored before returning
+    g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+    for lim in (120, 30, 400):
+        assert g.simplex(it_lim=lim) == o.simplex(it_lim=lim)
+        assert g.pert_cnt == o.pert_cnt and g.bland_cnt == o.bland_cnt
+        assert_same_state(g, o, "degenerate, limit %d" % lim)
+    for P in (g, o):
+        P.simplex()
+    assert_same_state(g, o, "degenerate resumed")
+    # warm-started dual simplex on a degenerate vertex (children of the solved LP): Bland fallback territory
+    x = o.col_prim()
+    frac = [j + 1 for j in range(len(x)) if np.trunc(x[j]) != x[j]]
+    for j in frac[:4]:
+        for P in (g, o):
+            P.kid = P.copy()
+            P.api.set_col_bnds(P.kid.h, j, UP, 0.0, float(np.floor(x[j - 1])))
+            P.kid.simplex()
+        assert g.kid.bland_cnt == o.kid.bland_cnt and g.kid.pert_cnt == o.kid.pert_cnt
+        assert_same_state(g.kid, o.kid, "degenerate child %d" % j)
+
+
+@pytest.mark.parametrize("limit", [1, 2])
+def test_bland_fallback_bit_exact(gpu, orc, limit):
+    """With the stall limit forced down to 1-2 degenerate pivots the perturbation is spent early and Bland's
+    rule takes over in every phase (primal 2, primal 1, dual): same choices on both sides."""
+    try:
+        gpu.set_stall_limit(limit)
+        orc.set_stall_limit(limit)
+        rng = np.random.default_rng(7)
+        n_bland = n_pert = 0
+        for trial in range(120):
+            A, row_b, col_b, c, direction = lpgen.random_general_lp(rng)
+            g, o = gpu.create(), orc.create()
+            for P in (g, o):
+                P.load_general(A, row_b, col_b, c, c0=1.5, direction=direction)
+                P.rc = P.simplex()
+            assert g.rc == o.rc and g.bland_cnt == o.bland_cnt and g.pert_cnt == o.pert_cnt, trial
+            assert_same_state(g, o, "limit %d trial %d" % (limit, trial))
+            n_bland += o.bland_cnt
+            n_pert += o.pert_cnt
+        A, b, c = lpgen.degenerate_lp(60, 80, 2)
+        g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+        for P in (g, o):
+            assert P.simplex() == 0
+        assert g.bland_cnt == o.bland_cnt and g.pert_cnt == o.pert_cnt == 1
+        assert_same_state(g, o, "degenerate, limit %d" % limit)
+        n_bland += o.bland_cnt
+        assert n_pert >= 1
+        if limit == 1:
+            assert n_bland >= 5  # the fallback really ran
+    finally:
+        gpu.set_stall_limit(0)
+        orc.set_stall_limit(0)

@@ -95,3 +95,25 @@ def test_ilp_branch_and_bound_matches_milp(orc, case):
         assert rel(r["best_lower"], case["ilp_obj"]) <= RTOL
         x = np.array(r["x"])
         assert np.all(np.abs(x - np.round(x)) <= 1e-8) and np.all(A @ x <= b + 1e-7)
+
+
+@pytest.mark.parametrize("case", GOLD["degenerate"], ids=lambda g: g.get("name") or "%dx%d_s%d" % (g["m"], g["n"], g["seed"]))
+def test_stalling_lps_reach_the_optimum(orc, case):
+    """Cycling textbook LPs and massively degenerate ones: plain Dantzig pricing spins on them (chvatal,
+    150x150, 200x300, 250x400 never finish); the anti-stalling rules must end on HiGHS's optimum."""
+    if "name" in case:
+        A, b, c = (np.array(v, float) for v in lpgen.CYCLING[case["name"]])
+        P = orc.create()
+        P.load_dense(A, b, c)
+    else:
+        A, b, c = lpgen.degenerate_lp(case["m"], case["n"], case["seed"])
+        P = lpgen.load_degenerate(orc, A, b, c)
+    assert P.simplex() == 0
+    assert P.status == capi.OPT
+    assert rel(P.obj, case["obj"]) <= RTOL
+    x = P.col_prim()
+    assert np.all(x >= -1e-9) and np.all(A @ x <= b + 1e-7)
+    if case.get("name") == "chvatal":
+        assert P.pert_cnt == 1  # 64 degenerate pivots, then the perturbation
+    if case.get("m", 0) >= 150:
+        assert P.pert_cnt == 1 and P.it_cnt < 20000
