@@ -53,6 +53,10 @@ typedef struct mvx_lp_api {
   /* optional (may be NULL): solve `count` independent handles concurrently, same results as
      `count` simplex calls -- used for the two children of a branch (bs.cpp:279,287) */
   int (*simplex_batch)(void **probs, int count, const void *parm, int *rcs);
+  /* optional (may be NULL = maximisation): GLP_MIN / GLP_MAX.  bs.cpp compares bounds as a maximiser
+     (bs.cpp:172,210) whatever the direction; with reference_quirks = 0 the driver turns the compares
+     round for a minimisation problem */
+  int (*get_obj_dir)(const void *P);
 } mvx_lp_api;
 
 const mvx_lp_api *mvx_hip_lp_api(void);
@@ -68,7 +72,9 @@ typedef struct {
   int reference_quirks; /* 1 (default): bug-compatible with bs.cpp / util.cpp;
                            0: children keep the opposite bound (bs.cpp:274,282 drop it), the
                            integrality test has a 1e-9 tolerance, cuts are the repaired GMI of
-                           mvx_generateCutGMI and are not carried from node to node */
+                           mvx_generateCutGMI and are not carried from node to node, and a
+                           minimisation problem is bounded and pruned as one (best_lower is then the
+                           best upper bound) */
   int lazy_pool;        /* 1 (default): generate only the cut cut.cpp:20 will actually add (the last
                            eligible column's); 0: generate and pool every cut like bs.cpp:250-255 */
   int cut_select;       /* reference_quirks = 0 only (changes results, hence not the

@@ -246,9 +246,16 @@ private:
   const mvx_lp_api *_api;
 };
 
+// +1: compare bounds as a maximiser (bs.cpp:172,210 always do); -1: repaired mode on a minimisation problem
+inline double sense_of(const mvx_lp_api *api, const void *prob, const mvx_bnb_params &p) {
+  return (p.reference_quirks == 0 && api->get_obj_dir && api->get_obj_dir(prob) == MVX_MIN) ? -1.0 : 1.0;
+}
+
 class ParameterObj { // util.h:61-99
 public:
-  ParameterObj(const mvx_lp_api *api, const void *prob, const mvx_bnb_params &p) : _api(api), _prob(prob), _p(p) {}
+  ParameterObj(const mvx_lp_api *api, const void *prob, const mvx_bnb_params &p)
+      : _api(api), _prob(prob), _p(p), _sg(sense_of(api, prob, p)) {}
+  double sense() const { return _sg; }
   bool IsCutEnabled() const { return _p.cut_strat != 0; }
 
   std::shared_ptr<NodeData> pickNode(const std::deque<std::shared_ptr<NodeData>> &problems, int &index) const { // util.cpp:154-188
@@ -258,7 +265,7 @@ public:
     }
     index = 0;
     for (int i = 1; i < (int)problems.size(); i++)
-      if (problems[(size_t)index]->upperBound < problems[(size_t)i]->upperBound) index = i; // first maximum
+      if (_sg * problems[(size_t)index]->upperBound < _sg * problems[(size_t)i]->upperBound) index = i; // first maximum
     return problems.at((size_t)index);
   }
 
@@ -293,6 +300,7 @@ private:
   const mvx_lp_api *_api;
   const void *_prob;
   mvx_bnb_params _p;
+  double _sg;
 };
 } // namespace MVOLP
 
@@ -376,7 +384,8 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
   leafContainer.push_back(S1);
 
   void *a = api->create_prob();                                 // bs.cpp:89
-  double bestLower = -std::numeric_limits<double>::infinity();  // bs.cpp:90
+  const double sg = params.sense();
+  double bestLower = -sg * std::numeric_limits<double>::infinity(); // bs.cpp:90
   const int n0 = api->get_num_cols(prob);
   std::vector<double> xbest((size_t)n0 + 1, 0.0);
   int incumbent_oid = 0, has_incumbent = 0, hit_limit = 0;
@@ -415,7 +424,7 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
     if (status == 1) { // prune by integrality, bs.cpp:158-193
       rec.prune[(size_t)node->oid] = MVOLP::INTG;
       rec.emit(MVX_EV_INTEGER, node->oid, node->upperBound, 0.0, 0, 0);
-      if (node->upperBound > bestLower) {
+      if (sg * node->upperBound > sg * bestLower) {
         bestLower = node->upperBound;
         has_incumbent = 1;
         incumbent_oid = node->oid;
@@ -427,7 +436,7 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
       rec.prune[(size_t)node->oid] = MVOLP::FEAS;
       rec.emit(MVX_EV_INFEASIBLE, node->oid, 0.0, 0.0, 0, 0);
       leafContainer.erase(leafContainer.begin() + index);
-    } else if (api->get_obj_val(a) <= bestLower) { // bs.cpp:210-223 (ties pruned)
+    } else if (sg * api->get_obj_val(a) <= sg * bestLower) { // bs.cpp:210-223 (ties pruned)
       rec.prune[(size_t)node->oid] = MVOLP::BNDS;
       rec.emit(MVX_EV_FATHOMED, node->oid, 0.0, 0.0, 0, 0);
       leafContainer.erase(leafContainer.begin() + index);
@@ -565,7 +574,8 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
   S1->inital = true;
   rec.node(S1->oid, 0);
   leafContainer.push_back(S1);
-  double bestLower = -std::numeric_limits<double>::infinity();
+  const double sg = params.sense();
+  double bestLower = -sg * std::numeric_limits<double>::infinity();
   const int n0 = api->get_num_cols(prob);
   std::vector<double> xbest((size_t)n0 + 1, 0.0);
   int incumbent_oid = 0, has_incumbent = 0, hit_limit = 0, count = 0;
@@ -630,7 +640,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       if (status == 1) {
         rec.prune[(size_t)node->oid] = MVOLP::INTG;
         rec.emit(MVX_EV_INTEGER, node->oid, node->upperBound, 0.0, 0, 0);
-        if (node->upperBound > bestLower) {
+        if (sg * node->upperBound > sg * bestLower) {
           bestLower = node->upperBound;
           has_incumbent = 1;
           incumbent_oid = node->oid;
@@ -639,7 +649,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       } else if (status == -1) {
         rec.prune[(size_t)node->oid] = MVOLP::FEAS;
         rec.emit(MVX_EV_INFEASIBLE, node->oid, 0.0, 0.0, 0, 0);
-      } else if (api->get_obj_val(aw) <= bestLower) {
+      } else if (sg * api->get_obj_val(aw) <= sg * bestLower) {
         rec.prune[(size_t)node->oid] = MVOLP::BNDS;
         rec.emit(MVX_EV_FATHOMED, node->oid, 0.0, 0.0, 0, 0);
       } else {
@@ -746,6 +756,7 @@ const mvx_lp_api g_hip_api = {
     [](void **probs, int count, const void *parm, int *rcs) {
       return mvx_simplex_batch((mvx_prob **)probs, count, (const mvx_smcp *)parm, rcs);
     },
+    [](const void *P) { return mvx_get_obj_dir((const mvx_prob *)P); },
 };
 
 } // namespace

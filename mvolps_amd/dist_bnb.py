@@ -133,7 +133,9 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         local[1] = root.copy(capi.ON)  # S1 = NodeData(prob), bs.cpp:80
     next_id = 2
     child_seq = 0
-    best_lower, has_inc, inc_oid, inc_owner = NEG_INF, 0, 0, 0
+    # bs.cpp:172,210 compare as a maximiser; the repaired mode turns the compares round for a minimisation problem
+    sg = -1.0 if (not quirks and api.get_obj_dir(root.h) == capi.MIN) else 1.0
+    best_lower, has_inc, inc_oid, inc_owner = -sg * float("inf"), 0, 0, 0
     x_keep = {}
     count, hit_limit, total_pivots = 0, 0, 0
     n0 = root.n
@@ -196,12 +198,12 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
             if st == 1:
                 prune[nd.oid] = INTG
                 ev.append((EV_INTEGER, nd.oid, obj, 0.0, 0, 0))
-                if obj > best_lower:
+                if sg * obj > sg * best_lower:
                     best_lower, has_inc, inc_oid, inc_owner = obj, 1, nd.oid, nd.owner
             elif st == -1:
                 prune[nd.oid] = FEAS
                 ev.append((EV_INFEASIBLE, nd.oid, 0.0, 0.0, 0, 0))
-            elif obj <= best_lower:
+            elif sg * obj <= sg * best_lower:
                 prune[nd.oid] = BNDS
                 ev.append((EV_FATHOMED, nd.oid, 0.0, 0.0, 0, 0))
             else:

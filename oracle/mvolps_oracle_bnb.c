@@ -298,11 +298,11 @@ static void emit(ctx_t *cx, int type, int oid, double f6, double f7, int f8, int
 }
 
 /* util.cpp:154-188 */
-static int pick_node(const orc_bnb_params *pr, node_t **q, int nq) {
+static int pick_node(const orc_bnb_params *pr, node_t **q, int nq, double sg) {
   if (pr->node_strat == 0) return 0; /* "DFS" is problems.front(), util.cpp:165 */
   int best = 0;                      /* std::max_element: first maximum */
   for (int i = 1; i < nq; i++)
-    if (q[best]->upperBound < q[i]->upperBound) best = i;
+    if (sg * q[best]->upperBound < sg * q[i]->upperBound) best = i;
   return best;
 }
 
@@ -372,7 +372,10 @@ int orc_branchAndBound(orc_prob *prob, const orc_bnb_params *params, orc_bnb_res
   leaf[nq++] = S1;
 
   orc_prob *a = orc_create_prob(); /* bs.cpp:89 */
-  double bestLower = -HUGE_VAL;    /* bs.cpp:90 */
+  /* bs.cpp:172,210 compare as a maximiser whatever the direction; the repaired mode turns the compares
+     round for a minimisation problem (sg = -1) */
+  const double sg = (!params->reference_quirks && orc_get_obj_dir(prob) == ORC_MIN) ? -1.0 : 1.0;
+  double bestLower = -sg * HUGE_VAL; /* bs.cpp:90 */
   int count = 0;
 
   while (nq > 0) { /* bs.cpp:96 */
@@ -380,7 +383,7 @@ int orc_branchAndBound(orc_prob *prob, const orc_bnb_params *params, orc_bnb_res
       res->hit_limit = 1;
       break;
     }
-    int index = pick_node(params, leaf, nq);
+    int index = pick_node(params, leaf, nq, sg);
     node_t *node = leaf[index];
     orc_erase_prob(a);                       /* bs.cpp:114-115 */
     orc_copy_prob(a, node->prob, ORC_OFF);   /* bs.cpp:116 */
@@ -408,7 +411,7 @@ int orc_branchAndBound(orc_prob *prob, const orc_bnb_params *params, orc_bnb_res
     if (status == 1) { /* bs.cpp:158-193 */
       res->prune[node->oid] = 0;
       emit(&cx, ORC_EV_INTEGER, node->oid, node->upperBound, 0.0, 0, 0);
-      if (node->upperBound > bestLower) {
+      if (sg * node->upperBound > sg * bestLower) {
         bestLower = node->upperBound;
         res->has_incumbent = 1;
         res->incumbent_oid = node->oid;
@@ -418,7 +421,7 @@ int orc_branchAndBound(orc_prob *prob, const orc_bnb_params *params, orc_bnb_res
     } else if (status == -1) { /* bs.cpp:194-209 */
       res->prune[node->oid] = 1;
       emit(&cx, ORC_EV_INFEASIBLE, node->oid, 0.0, 0.0, 0, 0);
-    } else if (orc_get_obj_val(a) <= bestLower) { /* bs.cpp:210-223 */
+    } else if (sg * orc_get_obj_val(a) <= sg * bestLower) { /* bs.cpp:210-223 */
       res->prune[node->oid] = 3;
       emit(&cx, ORC_EV_FATHOMED, node->oid, 0.0, 0.0, 0, 0);
     } else { /* bs.cpp:224-324 */

@@ -68,9 +68,7 @@ def _worker(rank, world, port, outdir, case, kw, use_gpu):
             eng = dist_bnb.HipNodeEngine(0, comm_device="cpu")  # both ranks share cuda:0; gloo moves host copies
         else:
             eng = OracleNodeEngine()
-        m, n, seed, U = case
-        A, b, c, U = synth.dense_ilp(m, n, seed, U)
-        root = lpgen.load_ilp(eng.api, A, b, c, U)
+        root = lpgen.load_case(eng.api, tuple(case))
         res = dist_bnb.branch_and_bound(eng, root, **kw)
         with open(os.path.join(outdir, "rank%d.json" % rank), "w") as f:
             json.dump(res, f)

@@ -101,6 +101,17 @@ def degenerate_cases():
     return out
 
 
+def setcover_cases():
+    """Minimisation ILPs (set cover): optimum from HiGHS milp."""
+    out = []
+    for (m, n, seed) in [(15, 25, 1), (30, 40, 2), (40, 60, 3), (50, 80, 4)]:
+        A, c = lpgen.setcover_ilp(m, n, seed)
+        r = linprog(c, A_ub=-A, b_ub=-np.ones(m), bounds=(0, 1), method="highs-ds")
+        ri = milp(c, constraints=LinearConstraint(A, 1, np.inf), integrality=np.ones(n), bounds=Bounds(0, 1))
+        out.append({"m": m, "n": n, "seed": seed, "lp_obj": float(r.fun), "ilp_obj": float(ri.fun)})
+    return out
+
+
 def main():
     big = "--big" in sys.argv
     doc = {
@@ -110,11 +121,12 @@ def main():
         "general": general_cases(),
         "ilp": ilp_cases(),
         "degenerate": degenerate_cases(),
+        "setcover": setcover_cases(),
     }
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(doc, f, indent=1)
-    print("wrote golden.json: %d dense, %d general, %d ilp, %d degenerate" % (len(doc["dense"]), len(doc["general"]), len(doc["ilp"]),
-                                                                            len(doc["degenerate"])))
+    print("wrote golden.json: %d dense, %d general, %d ilp, %d degenerate, %d setcover" % (len(doc["dense"]), len(doc["general"]), len(doc["ilp"]),
+                                                                                         len(doc["degenerate"]), len(doc["setcover"])))
 
 
 if __name__ == "__main__":

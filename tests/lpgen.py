@@ -74,3 +74,32 @@ CYCLING = {
     "beale": ([[0.25, -8, -1, 9], [0.5, -12, -0.5, 3], [0, 0, 1, 0]], [0, 0, 1.0], [0.75, -20, 0.5, -6]),
     "chvatal": ([[0.5, -5.5, -2.5, 9], [0.5, -1.5, -0.5, 1], [1, 0, 0, 0]], [0, 0, 1.0], [10, -57, -9, -24.0]),
 }
+
+
+def setcover_ilp(m, n, seed, dens=0.15):
+    """min c x, A x >= 1, x binary (A 0/1, every row covered): a MINIMISATION ILP -- bs.cpp bounds and prunes as a
+    maximiser whatever the direction (bs.cpp:172,210), so only the repaired mode gets these right."""
+    rng = np.random.default_rng(seed)
+    A = (rng.random((m, n)) < dens).astype(float)
+    for i in range(m):
+        if A[i].sum() == 0:
+            A[i, rng.integers(n)] = 1.0
+    c = rng.integers(1, 10, size=n).astype(float)
+    return A, c
+
+
+def load_setcover(api, A, c):
+    from mvolps_amd.capi import DB, IV, LO, MIN
+    m, n = A.shape
+    P = api.create()
+    P.load_general(A, [(LO, 1.0, 0.0)] * m, [(DB, 0.0, 1.0)] * n, c, kinds=[IV] * n, direction=MIN)
+    return P
+
+
+def load_case(api, case):
+    """(m, n, seed, U) -> dense_ilp; ("setcover", m, n, seed) -> setcover_ilp"""
+    from mvolps_amd import synth
+    if case[0] == "setcover":
+        return load_setcover(api, *setcover_ilp(*case[1:]))
+    A, b, c, U = synth.dense_ilp(*case)
+    return load_ilp(api, A, b, c, U)

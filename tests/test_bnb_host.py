@@ -160,3 +160,22 @@ def test_repaired_gmi_cuts_keep_the_optimum_and_match_oracle(orc, cut_select, cu
         plain = bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), table=tab, node_strat=1, quirks=0)
         assert abs(got["best_lower"] - case["ilp_obj"]) <= 1e-9 * abs(case["ilp_obj"])
         assert got["count"] < plain["count"]  # the cuts do prune
+
+
+@pytest.mark.parametrize("window", [1, 64])
+@pytest.mark.parametrize("node_strat", [0, 1])
+def test_minimisation_problem_in_repaired_mode(orc, node_strat, window):
+    """Direction-aware bounding (reference_quirks = 0): the C++ driver and the oracle's restatement agree on a
+    minimisation ILP, in queue order, best-bound order and window mode; bug-compatible mode keeps bs.cpp's
+    maximiser compares on both sides."""
+    from oracle import oracle
+
+    A, c = lpgen.setcover_ilp(30, 40, 2)
+    tab = oracle_table(orc)
+    ref = oracle.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=0, node_strat=node_strat, max_nodes=5000)
+    got = bnb.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=0, node_strat=node_strat, max_nodes=5000, table=tab, window=window)
+    same_result(got, ref)
+    assert got["best_lower"] == 33.0
+    refq = oracle.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=1, node_strat=node_strat, max_nodes=300)
+    gotq = bnb.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=1, node_strat=node_strat, max_nodes=300, table=tab, window=window)
+    same_result(gotq, refq)

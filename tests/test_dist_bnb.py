@@ -36,6 +36,17 @@ def test_world2_matches_serial(orc, tmp_path, quirks, max_nodes, per_rank):
     assert serial["count"] > 20
 
 
+def test_world2_minimisation_problem(orc, tmp_path):
+    """Repaired mode on a minimisation ILP: the coordinator turns the incumbent / prune compares round like the
+    serial driver does."""
+    case = ("setcover", 30, 40, 2)
+    serial = canon(bnb.branch_and_bound(lpgen.load_case(orc, case), quirks=0, table=bnb.table_from(orc)))
+    res = dist_helpers.run_world(2, case, dict(quirks=0, per_rank=2), str(tmp_path))
+    assert_same(res[0], res[1])
+    assert_same(res[0], serial)
+    assert serial["best_lower"] == 33.0
+
+
 def test_world1_is_the_serial_driver(orc):
     """No process group: the coordinator degenerates to the serial loop."""
     from mvolps_amd import dist_bnb

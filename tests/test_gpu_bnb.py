@@ -142,3 +142,16 @@ def test_repaired_gmi_cuts_on_gpu(gpu, orc):
         got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), **kw)
         same_result(got, ref)
         assert abs(got["best_lower"] - case["ilp_obj"]) <= 1e-9 * abs(case["ilp_obj"])
+
+
+def test_minimisation_ilp_on_gpu(gpu, orc):
+    """Set-cover (min) in repaired mode: dual simplex from the slack basis, direction-aware bounding; device
+    driver (window and node-at-a-time, queue and best-bound order) against the oracle's restatement."""
+    from oracle import oracle
+
+    A, c = lpgen.setcover_ilp(40, 60, 3)
+    for node_strat, window in ((0, 64), (0, 1), (1, 1)):
+        ref = oracle.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=0, node_strat=node_strat, max_nodes=5000)
+        got = bnb.branch_and_bound(lpgen.load_setcover(gpu, A, c), quirks=0, node_strat=node_strat, max_nodes=5000, window=window)
+        same_result(got, ref)
+        assert abs(got["best_lower"] - 22.0) < 1e-9

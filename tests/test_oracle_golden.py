@@ -117,3 +117,21 @@ def test_stalling_lps_reach_the_optimum(orc, case):
         assert P.pert_cnt == 1  # 64 degenerate pivots, then the perturbation
     if case.get("m", 0) >= 150:
         assert P.pert_cnt == 1 and P.it_cnt < 20000
+
+
+@pytest.mark.parametrize("case", GOLD["setcover"], ids=lambda g: "%dx%d_s%d" % (g["m"], g["n"], g["seed"]))
+def test_minimisation_ilp_repaired_mode_matches_milp(orc, case):
+    """Set-cover ILPs (min): LP relaxation through the dual simplex from the slack basis, and the repaired
+    branch-and-bound, which bounds and prunes a minimisation problem as one (bs.cpp:172,210 never do)."""
+    from oracle import oracle
+
+    A, c = lpgen.setcover_ilp(case["m"], case["n"], case["seed"])
+    P = lpgen.load_setcover(orc, A, c)
+    assert P.simplex() == 0 and P.status == capi.OPT
+    assert rel(P.obj, case["lp_obj"]) <= RTOL
+    for node_strat in (0, 1):
+        r = oracle.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=0, node_strat=node_strat, max_nodes=50000)
+        assert r["has_incumbent"] and not r["hit_limit"]
+        assert rel(r["best_lower"], case["ilp_obj"]) <= RTOL
+        x = np.array(r["x"])[-A.shape[1]:]
+        assert np.all(A @ x >= 1 - 1e-7) and rel(float(c @ x), case["ilp_obj"]) <= RTOL
