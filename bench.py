@@ -135,7 +135,7 @@ def cpu_baseline(m, n, seed, budget_s=9.0, max_pivots=400):
 
 def secondary(api):
     """Other BASELINE configs on the same GPU, reported beside the headline (not part of `value`)."""
-    from mvolps_amd import dist_bnb, synth
+    from mvolps_amd import bnb, dist_bnb, synth
     from tests import lpgen
 
     out = {}
@@ -151,15 +151,21 @@ def secondary(api):
     el = time.perf_counter() - t0
     out["dense_lp_1024x2048"] = {"pivots_per_s": 800 / el, "us_per_pivot": el / 800 * 1e6,
                                  "frac_of_hbm_roofline": 800 / el * bytes_per_pivot(1024, 2048) / 1e9 / HBM_PEAK_GBS}
-    # configs 3/5 shape: ILP 512x1024, FIFO B&B through the window coordinator (64 node LPs share each launch)
+    # configs 3/5 shape: ILP 512x1024, FIFO B&B.  mvx_branchAndBound in window mode (64 node LPs share each launch)
+    # and the multi-rank coordinator on one rank (same tree, Python replay of the decisions)
     A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3)
-    eng = dist_bnb.HipNodeEngine(0)
-    dist_bnb.branch_and_bound(eng, lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=64, per_rank=32)  # warm-up
+    bnb.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=64)  # warm-up
     t0 = time.perf_counter()
-    r = dist_bnb.branch_and_bound(eng, lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=1500, per_rank=32)
+    r = bnb.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=2000)
     el = time.perf_counter() - t0
-    out["bnb_ilp_512x1024"] = {"nodes": r["count"], "nodes_per_s": r["count"] / el, "pivots": r["total_pivots"],
-                               "pivots_per_s": r["total_pivots"] / el, "window": 32}
+    out["bnb_ilp_512x1024"] = {"driver": "mvx_branchAndBound", "nodes": r["count"], "nodes_per_s": r["count"] / el,
+                               "pivots": r["total_pivots"], "pivots_per_s": r["total_pivots"] / el, "window": 64}
+    eng = dist_bnb.HipNodeEngine(0)
+    t0 = time.perf_counter()
+    r2 = dist_bnb.branch_and_bound(eng, lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=2000, per_rank=64)
+    el = time.perf_counter() - t0
+    out["bnb_ilp_512x1024_coordinator"] = {"driver": "mvolps_amd.dist_bnb (1 rank)", "nodes": r2["count"], "nodes_per_s": r2["count"] / el,
+                                           "pivots": r2["total_pivots"], "same_tree": r2["prune"] == r["prune"], "per_rank": 64}
     return out
 
 
