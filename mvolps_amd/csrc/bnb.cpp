@@ -411,10 +411,17 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
         rec.prune[(size_t)node->oid] = MVOLP::FEAS;
         break;
       }
-      if (status == 1) { // bs.cpp:144-149
+      if (status == 1) { // bs.cpp:144-149: leaves without recording the solution; repaired mode keeps it
         node->upperBound = api->get_obj_val(a);
         rec.bound[(size_t)node->oid] = node->upperBound;
         rec.prune[(size_t)node->oid] = MVOLP::INTG;
+        if (!quirks) {
+          bestLower = node->upperBound;
+          has_incumbent = 1;
+          incumbent_oid = node->oid;
+          const int na = api->get_num_cols(a);
+          for (int i = 1; i <= na && i <= n0; i++) xbest[(size_t)i] = api->get_col_prim(a, i);
+        }
         break;
       }
     }
@@ -631,6 +638,12 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
           node->upperBound = api->get_obj_val(aw);
           rec.bound[(size_t)node->oid] = node->upperBound;
           rec.prune[(size_t)node->oid] = MVOLP::INTG;
+          if (!quirks) { // bs.cpp:144-149 leaves without recording the solution; repaired mode keeps it
+            bestLower = node->upperBound;
+            has_incumbent = 1;
+            incumbent_oid = node->oid;
+            for (int i = 1; i <= n0; i++) xbest[(size_t)i] = api->get_col_prim(aw, i);
+          }
           stop = true;
           break;
         }

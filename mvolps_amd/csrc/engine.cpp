@@ -59,6 +59,7 @@ struct SolveCtx {
   double *d_colq = nullptr, *d_srow = nullptr, *d_cost1 = nullptr, *d_wts = nullptr, *d_part = nullptr, *d_rcbase = nullptr;
   int *d_gflag = nullptr;
   double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
+  double *d_dw = nullptr; // dual devex weights by row
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
@@ -167,6 +168,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_pp0 = carve((size_t)fused_npb(l) * sizeof(Cand)), o_pp1 = carve((size_t)fused_npb(l) * sizeof(Cand));
   size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
   size_t o_olb = carve((size_t)(mc + l + 1) * 8), o_oub = carve((size_t)(mc + l + 1) * 8);
+  size_t o_dw = carve((size_t)(mc + 1) * 8);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -186,6 +188,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_rp = (Cand *)(b + o_rp);
   sc.d_olb = (double *)(b + o_olb);
   sc.d_oub = (double *)(b + o_oub);
+  sc.d_dw = (double *)(b + o_dw);
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
@@ -362,7 +365,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->tol_bnd = 1e-9; h->tol_dj = 1e-9; h->tol_piv = 1e-9;
   h->phase = PH_START; h->done = D_RUN; h->budget = -1;
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
-  h->olb = sc.d_olb; h->oub = sc.d_oub;
+  h->olb = sc.d_olb; h->oub = sc.d_oub; h->dw = sc.d_dw;
   h->colqx[0] = sc.d_colqx[0]; h->colqx[1] = sc.d_colqx[1];
   h->betac[0] = sc.d_betac[0]; h->betac[1] = sc.d_betac[1];
   h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
@@ -732,12 +735,14 @@ static bool job_collect(Context &c, SolveJob &J) {
   return false;
 }
 
-// A handle whose last solve ended OPT / NOFEAS / UNBND and that has not been edited since (every
-// edit resets `status`) would go through zero pivots and come out unchanged: bs.cpp:116-117 re-solves
-// exactly such clones at every pop.  Answer from the state at hand instead of queueing launches.
+// A handle whose last solve ended OPT / UNBND and that has not been edited since (every edit resets
+// `status`) would go through zero pivots and come out unchanged: bs.cpp:116-117 re-solves exactly such
+// clones at every pop.  Answer from the state at hand instead of queueing launches.  NOFEAS is not in
+// the list: the dual simplex restarts its devex weights on entry, so the re-solve may pick another
+// infeasible row than the one that proved infeasibility and pivot on before it ends NOFEAS again.
 static bool already_solved(const mvx_prob *P, const mvx_smcp &parm) {
   if (!P->valid || parm.it_lim == 0) return false;
-  if (P->status != MVX_OPT && P->status != MVX_NOFEAS && P->status != MVX_UNBND) return false;
+  if (P->status != MVX_OPT && P->status != MVX_UNBND) return false;
   return P->last_tol[0] == parm.tol_bnd && P->last_tol[1] == parm.tol_dj && P->last_tol[2] == parm.tol_piv;
 }
 static void remember_tolerances(mvx_prob *P, const mvx_smcp &parm) {
@@ -817,7 +822,7 @@ static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
   HIPCHECK(hipMalloc((void **)&bc.d_ctl, sizeof(Ctl) * bc.slots));
   HIPCHECK(hipHostMalloc((void **)&bc.h_ctl, sizeof(Ctl) * bc.slots));
   bc.scratch_stride = align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256) +
-                      2 * align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256);
+                      2 * align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) + align_up((size_t)(bc.m_cap + 1) * 8, 256);
   HIPCHECK(hipMalloc((void **)&bc.scratch, bc.scratch_stride * bc.slots));
   HIPCHECK(hipMemsetAsync(bc.scratch, 0, bc.scratch_stride * bc.slots, bc.stream));
   bc.stage_stride = stage_size(bc.m_cap, bc.ld);
@@ -840,6 +845,7 @@ static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &pa
   h->srow = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256));
   h->olb = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256));
   h->oub = h->olb + align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) / 8;
+  h->dw = h->oub + align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) / 8;
   h->m = P->m; h->n = P->n; h->ld = P->ld; h->m_cap = P->m_cap;
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = parm.tol_bnd; h->tol_dj = parm.tol_dj; h->tol_piv = parm.tol_piv;

@@ -84,6 +84,7 @@ struct KC {
   double *colq, *srow;
   int *bvar, *nvar;
   double *olb, *oub;
+  double *dw; // dual devex weights by row
   int bland; // Bland's rule in force (stall >= stall_limit)
   int m, n, ld;
   double tol_bnd, tol_dj, tol_piv, sgn;
@@ -96,13 +97,17 @@ __device__ __forceinline__ KC load_kc(const Ctl *c) {
   k.colq = c->colq; k.srow = c->srow;
   k.bvar = c->bvar; k.nvar = c->nvar;
   k.olb = c->olb; k.oub = c->oub;
+  k.dw = c->dw;
   k.bland = c->stall >= c->stall_limit;
   k.m = c->m; k.n = c->n; k.ld = c->ld;
   k.tol_bnd = c->tol_bnd; k.tol_dj = c->tol_dj; k.tol_piv = c->tol_piv; k.sgn = c->sgn;
   return k;
 }
 
-__device__ Cand dev_infeas_row(const KC &k, Cand *lds) {
+// Leaving row of the dual simplex / primal feasibility check.  Score of an infeasible row: viol^2 / w[i]
+// (dual devex weights; w == nullptr: all ones), lowest row on ties; under Bland's rule the lowest
+// variable number (oracle: select_infeasible_row).
+__device__ Cand dev_infeas_row(const KC &k, Cand *lds, const double *w) {
   Cand best{0.0, 0.0, 0, 0};
   const size_t ld = (size_t)k.ld;
   const double tol = k.tol_bnd;
@@ -117,7 +122,7 @@ __device__ Cand dev_infeas_row(const KC &k, Cand *lds) {
       up = 1;
     }
     if (viol > 0.0) {
-      Cand x{k.bland ? -(double)k.bvar[i] : viol, 0.0, i, up}; // Bland: lowest variable number wins
+      Cand x{k.bland ? -(double)k.bvar[i] : viol * viol / (w ? w[i] : 1.0), 0.0, i, up}; // Bland: lowest variable number wins
       if (cand_better<0>(x, best)) best = x;
     }
   }
@@ -379,9 +384,10 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
   if (c->done != D_RUN) return;
   int phase = c->phase, rounds = c->rounds;
   int p = 0, p_up = 0, q = 0, sdir = 0, kind = 0; // kind 1 primal, 2 dual
+  bool fresh_dual = false; // the dual phase starts with this step: devex weights restart from one
   for (;;) {
     if (phase == PH_START) {
-      Cand r = dev_infeas_row(k, lds);
+      Cand r = dev_infeas_row(k, lds, nullptr);
       if (r.idx == 0) {
         phase = PH_PRIMAL2;
       } else {
@@ -394,6 +400,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
         p = r.idx;
         p_up = r.aux;
         kind = 2;
+        fresh_dual = true;
         break;
       }
     }
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
         }
         return;
       }
-      Cand r = dev_infeas_row(k, lds);
+      Cand r = dev_infeas_row(k, lds, nullptr);
       if (r.idx == 0) {
         dev_finish(c, D_OPT, phase, rounds);
         return;
@@ -439,10 +446,11 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
       p = r.idx;
       p_up = r.aux;
       kind = 2;
+      fresh_dual = true;
       break;
     }
     if (phase == PH_DUAL) {
-      Cand r = dev_infeas_row(k, lds);
+      Cand r = dev_infeas_row(k, lds, k.dw);
       if (r.idx != 0) {
         p = r.idx;
         p_up = r.aux;
@@ -468,6 +476,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
       return;
     }
   } else {
+    const double wp = fresh_dual ? 1.0 : k.dw[p]; // read by every lane before its owner rewrites it below
     Cand dr = dev_dual_ratio(k, p, p_up, lds);
     if (dr.idx == 0) {
       dev_finish(c, D_NOFEAS, phase, rounds);
@@ -475,7 +484,23 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
     }
     q = dr.idx;
     const size_t ld = (size_t)k.ld;
-    for (int i = TIDX; i <= k.m; i += (int)blockDim.x) k.colq[i] = k.T[(size_t)i * ld + q];
+    const double apq = k.T[(size_t)p * ld + q];
+    // pivot column copy + devex weight update (oracle: dual_simplex), one pass over the rows
+    for (int i = TIDX; i <= k.m; i += (int)blockDim.x) {
+      const double a = k.T[(size_t)i * ld + q];
+      k.colq[i] = a;
+      if (i == 0) continue;
+      if (i == p) {
+        const double cc = wp / (apq * apq);
+        k.dw[i] = cc > 1.0 ? cc : 1.0;
+      } else {
+        const double r = a / apq;
+        const double cc = r * r * wp;
+        double wi = fresh_dual ? 1.0 : k.dw[i];
+        if (cc > wi) wi = cc;
+        k.dw[i] = wi;
+      }
+    }
     dev_prepare_pivot(k, c, p, q, p_up);
     if (TIDX == 0) {
       if (k.bland) c->n_bland++;

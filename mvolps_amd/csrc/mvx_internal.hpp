@@ -78,6 +78,7 @@ struct Ctl {
   // variable number, saved when the perturbation is applied
   double *olb, *oub;
   int perturbed, pert_used, n_pert;
+  double *dw; // [m_cap+1] dual devex reference weights by row (oracle: dual_simplex's w), reset on entering the dual phase
   int stall_new; // fused path: k_fa's verdict on the step it prepared, committed by k_fb (k_fa workgroups read `stall`)
   double ent_lb, ent_ub;
 };

@@ -187,10 +187,12 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
                     prune[nd.oid] = FEAS
                     stop_all = True
                     break
-                if st == 1:  # bs.cpp:144-149
+                if st == 1:  # bs.cpp:144-149 (leaves without recording the solution; repaired mode keeps it)
                     nd.upper = obj
                     bound[nd.oid] = obj
                     prune[nd.oid] = INTG
+                    if not quirks:
+                        best_lower, has_inc, inc_oid, inc_owner = obj, 1, nd.oid, nd.owner
                     stop_all = True
                     break
             nd.upper = obj

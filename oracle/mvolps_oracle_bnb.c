@@ -397,10 +397,17 @@ int orc_branchAndBound(orc_prob *prob, const orc_bnb_params *params, orc_bnb_res
         res->prune[node->oid] = 1;
         break;
       }
-      if (status == 1) { /* bs.cpp:144-149 */
+      if (status == 1) { /* bs.cpp:144-149: leaves without recording the solution; repaired mode keeps it */
         node->upperBound = orc_get_obj_val(a);
         res->node_bound[node->oid] = node->upperBound;
         res->prune[node->oid] = 0;
+        if (!params->reference_quirks) {
+          bestLower = node->upperBound;
+          res->has_incumbent = 1;
+          res->incumbent_oid = node->oid;
+          int na = orc_get_num_cols(a);
+          for (int i = 1; i <= na && i <= n0; i++) res->x[i] = orc_get_col_prim(a, i);
+        }
         break;
       }
     }

@@ -170,12 +170,17 @@ def test_minimisation_problem_in_repaired_mode(orc, node_strat, window):
     maximiser compares on both sides."""
     from oracle import oracle
 
-    A, c = lpgen.setcover_ilp(30, 40, 2)
+    A, c = lpgen.setcover_ilp(40, 60, 3)
     tab = oracle_table(orc)
     ref = oracle.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=0, node_strat=node_strat, max_nodes=5000)
     got = bnb.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=0, node_strat=node_strat, max_nodes=5000, table=tab, window=window)
     same_result(got, ref)
-    assert got["best_lower"] == 33.0
+    assert abs(got["best_lower"] - 22.0) < 1e-9 and got["count"] > 3
+    # an LP relaxation that is integral at the root: bs.cpp:144-149 leaves without recording it, repaired mode keeps it
+    A2, c2 = lpgen.setcover_ilp(30, 40, 2)
+    r2 = bnb.branch_and_bound(lpgen.load_setcover(orc, A2, c2), quirks=0, node_strat=node_strat, table=tab, window=window)
+    same_result(r2, oracle.branch_and_bound(lpgen.load_setcover(orc, A2, c2), quirks=0, node_strat=node_strat))
+    assert r2["count"] == 0 and r2["has_incumbent"] and r2["best_lower"] == 33.0 and r2["incumbent_oid"] == 1
     refq = oracle.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=1, node_strat=node_strat, max_nodes=300)
     gotq = bnb.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=1, node_strat=node_strat, max_nodes=300, table=tab, window=window)
     same_result(gotq, refq)

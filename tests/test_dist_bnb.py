@@ -39,12 +39,12 @@ def test_world2_matches_serial(orc, tmp_path, quirks, max_nodes, per_rank):
 def test_world2_minimisation_problem(orc, tmp_path):
     """Repaired mode on a minimisation ILP: the coordinator turns the incumbent / prune compares round like the
     serial driver does."""
-    case = ("setcover", 30, 40, 2)
+    case = ("setcover", 40, 60, 3)
     serial = canon(bnb.branch_and_bound(lpgen.load_case(orc, case), quirks=0, table=bnb.table_from(orc)))
     res = dist_helpers.run_world(2, case, dict(quirks=0, per_rank=2), str(tmp_path))
     assert_same(res[0], res[1])
     assert_same(res[0], serial)
-    assert serial["best_lower"] == 33.0
+    assert abs(serial["best_lower"] - 22.0) < 1e-9 and serial["count"] > 3
 
 
 def test_world1_is_the_serial_driver(orc):
@@ -57,6 +57,12 @@ def test_world1_is_the_serial_driver(orc):
         got = canon(dist_bnb.branch_and_bound(eng, lpgen.load_ilp(orc, A, b, c, U), var_strat=vs, quirks=0))
         ref = canon(bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), var_strat=vs, quirks=0, table=bnb.table_from(orc)))
         assert_same(got, ref)
+    # integral at the root (repaired mode keeps the solution, bs.cpp:144-149 drops it)
+    case = ("setcover", 30, 40, 2)
+    got = canon(dist_bnb.branch_and_bound(eng, lpgen.load_case(orc, case), quirks=0))
+    ref = canon(bnb.branch_and_bound(lpgen.load_case(orc, case), quirks=0, table=bnb.table_from(orc)))
+    assert_same(got, ref)
+    assert got["count"] == 0 and got["has_incumbent"] and got["best_lower"] == 33.0
 
 
 def test_pack_unpack_roundtrip(orc):
