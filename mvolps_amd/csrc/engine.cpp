@@ -60,6 +60,7 @@ struct SolveCtx {
   int *d_gflag = nullptr;
   double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
   double *d_dw = nullptr; // dual devex weights by row
+  double *d_pw[2] = {nullptr, nullptr}; // primal devex weights by column, two sets (fused path ping-pong)
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
@@ -169,6 +170,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
   size_t o_olb = carve((size_t)(mc + l + 1) * 8), o_oub = carve((size_t)(mc + l + 1) * 8);
   size_t o_dw = carve((size_t)(mc + 1) * 8);
+  size_t o_pw0 = carve((size_t)l * 8), o_pw1 = carve((size_t)l * 8);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -189,6 +191,8 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_olb = (double *)(b + o_olb);
   sc.d_oub = (double *)(b + o_oub);
   sc.d_dw = (double *)(b + o_dw);
+  sc.d_pw[0] = (double *)(b + o_pw0);
+  sc.d_pw[1] = (double *)(b + o_pw1);
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
@@ -366,6 +370,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->phase = PH_START; h->done = D_RUN; h->budget = -1;
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->olb = sc.d_olb; h->oub = sc.d_oub; h->dw = sc.d_dw;
+  h->pw[0] = sc.d_pw[0]; h->pw[1] = sc.d_pw[1];
   h->colqx[0] = sc.d_colqx[0]; h->colqx[1] = sc.d_colqx[1];
   h->betac[0] = sc.d_betac[0]; h->betac[1] = sc.d_betac[1];
   h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
@@ -822,7 +827,8 @@ static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
   HIPCHECK(hipMalloc((void **)&bc.d_ctl, sizeof(Ctl) * bc.slots));
   HIPCHECK(hipHostMalloc((void **)&bc.h_ctl, sizeof(Ctl) * bc.slots));
   bc.scratch_stride = align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256) +
-                      2 * align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) + align_up((size_t)(bc.m_cap + 1) * 8, 256);
+                      2 * align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) + align_up((size_t)(bc.m_cap + 1) * 8, 256) +
+                      align_up((size_t)bc.ld * 8, 256);
   HIPCHECK(hipMalloc((void **)&bc.scratch, bc.scratch_stride * bc.slots));
   HIPCHECK(hipMemsetAsync(bc.scratch, 0, bc.scratch_stride * bc.slots, bc.stream));
   bc.stage_stride = stage_size(bc.m_cap, bc.ld);
@@ -846,6 +852,7 @@ static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &pa
   h->olb = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256));
   h->oub = h->olb + align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) / 8;
   h->dw = h->oub + align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) / 8;
+  h->pw[0] = h->pw[1] = h->dw + align_up((size_t)(bc.m_cap + 1) * 8, 256) / 8; // generic path only: one set
   h->m = P->m; h->n = P->n; h->ld = P->ld; h->m_cap = P->m_cap;
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = parm.tol_bnd; h->tol_dj = parm.tol_dj; h->tol_piv = parm.tol_piv;

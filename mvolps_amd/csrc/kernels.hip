@@ -85,6 +85,7 @@ struct KC {
   int *bvar, *nvar;
   double *olb, *oub;
   double *dw; // dual devex weights by row
+  double *pw; // primal devex weights by column (current set)
   int bland; // Bland's rule in force (stall >= stall_limit)
   int m, n, ld;
   double tol_bnd, tol_dj, tol_piv, sgn;
@@ -98,6 +99,7 @@ __device__ __forceinline__ KC load_kc(const Ctl *c) {
   k.bvar = c->bvar; k.nvar = c->nvar;
   k.olb = c->olb; k.oub = c->oub;
   k.dw = c->dw;
+  k.pw = c->pw[c->curA & 1];
   k.bland = c->stall >= c->stall_limit;
   k.m = c->m; k.n = c->n; k.ld = c->ld;
   k.tol_bnd = c->tol_bnd; k.tol_dj = c->tol_dj; k.tol_piv = c->tol_piv; k.sgn = c->sgn;
@@ -129,7 +131,9 @@ __device__ Cand dev_infeas_row(const KC &k, Cand *lds, const double *w) {
   return block_best<0>(best, lds);
 }
 
-__device__ Cand dev_price(const KC &k, const double *cost, double sgn, Cand *lds) {
+// Entering column.  mode 0: Dantzig (largest |d_j|; phase 1 and existence checks), 1: devex with the
+// current weights (d_j^2 / pw[j]), 2: devex with all weights one.  Bland's rule overrides both.
+__device__ Cand dev_price(const KC &k, const double *cost, double sgn, Cand *lds, int mode = 0) {
   Cand best{0.0, 0.0, 0, 0};
   const double tol = k.tol_dj;
   for (int j = 1 + TIDX; j <= k.n; j += (int)blockDim.x) {
@@ -139,7 +143,8 @@ __device__ Cand dev_price(const KC &k, const double *cost, double sgn, Cand *lds
     const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
     const bool dn = (f == MVX_NU || f == MVX_NF) && dj < -tol;
     if (!up && !dn) continue;
-    Cand x{k.bland ? -(double)k.nvar[j] : fabs(dj), 0.0, j, up ? 1 : -1};
+    const double sc = k.bland ? -(double)k.nvar[j] : (mode == 0 ? fabs(dj) : dj * dj / (mode == 1 ? k.pw[j] : 1.0));
+    Cand x{sc, 0.0, j, up ? 1 : -1};
     if (cand_better<0>(x, best)) best = x;
   }
   return block_best<0>(best, lds);
@@ -234,13 +239,27 @@ __device__ __forceinline__ int dev_leave_flag(double lb, double ub, int to_upper
 }
 
 // Scale the pivot row into srow and publish the pivot description.  All threads call.
-__device__ void dev_prepare_pivot(const KC &k, Ctl *c, int p, int q, int p_up) {
+// wmode 0: leave the primal devex weights alone (dual and phase-1 pivots); 1: update them from the pivot
+// row with pw[q] = wq (read by the caller before any lane can overwrite it); 2: same from all-one weights.
+__device__ void dev_prepare_pivot(const KC &k, Ctl *c, int p, int q, int p_up, int wmode = 0, double wq = 1.0) {
   const double *rowp = k.T + (size_t)p * k.ld;
   const double piv = rowp[q];
   const double bound = p_up ? k.bub[p] : k.blb[p];
   for (int j = TIDX; j <= k.n; j += (int)blockDim.x) {
     const double v = rowp[j];
-    k.srow[j] = (j == 0) ? (v - bound) / piv : v / piv;
+    const double sj = (j == 0) ? (v - bound) / piv : v / piv;
+    k.srow[j] = sj;
+    if (wmode && j >= 1) {
+      if (j == q) {
+        const double cc = wq / (piv * piv);
+        k.pw[j] = cc > 1.0 ? cc : 1.0;
+      } else {
+        const double cc = sj * sj * wq;
+        double wj = (wmode == 1) ? k.pw[j] : 1.0;
+        if (cc > wj) wj = cc;
+        k.pw[j] = wj;
+      }
+    }
   }
   if (TIDX == 0) {
     c->step = ST_PIVOT;
@@ -256,7 +275,8 @@ __device__ void dev_prepare_pivot(const KC &k, Ctl *c, int p, int q, int p_up) {
 
 // Entering column chosen: ratio test, then bound flip (done here) or pivot preparation.
 // Returns false when no row blocks (unbounded ray).
-__device__ bool dev_primal_step(const KC &k, Ctl *c, int q, int sdir, const int *g, Cand *lds) {
+__device__ bool dev_primal_step(const KC &k, Ctl *c, int q, int sdir, const int *g, Cand *lds, int wmode = 0) {
+  const double wq = (wmode == 1) ? k.pw[q] : 1.0; // every lane reads it ahead of the barriers inside the ratio test
   Cand r = dev_primal_ratio(k, q, sdir, g, lds);
   const double lbq = k.nlb[q], ubq = k.nub[q];
   const int fq = k.nflag[q];
@@ -268,6 +288,8 @@ __device__ bool dev_primal_step(const KC &k, Ctl *c, int q, int sdir, const int 
       const size_t ld = (size_t)k.ld;
       for (int i = TIDX; i <= k.m; i += (int)blockDim.x)
         k.T[(size_t)i * ld] = fma(k.colq[i], delta, k.T[(size_t)i * ld]);
+      if (wmode == 2) // a flip on the first step of the phase: the weights still have to start from one
+        for (int j = TIDX; j <= k.n; j += (int)blockDim.x) k.pw[j] = 1.0;
       if (TIDX == 0) {
         k.nflag[q] = (sdir > 0) ? MVX_NU : MVX_NL;
         c->step = ST_FLIP;
@@ -278,7 +300,7 @@ __device__ bool dev_primal_step(const KC &k, Ctl *c, int q, int sdir, const int 
     }
   }
   if (r.idx == 0) return false;
-  dev_prepare_pivot(k, c, r.idx, q, r.aux);
+  dev_prepare_pivot(k, c, r.idx, q, r.aux, wmode, wq);
   if (TIDX == 0) {
     if (k.bland) c->n_bland++;
     c->stall = (r.k1 <= DEGEN_TOL) ? c->stall + 1 : 0;
@@ -385,11 +407,13 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
   int phase = c->phase, rounds = c->rounds;
   int p = 0, p_up = 0, q = 0, sdir = 0, kind = 0; // kind 1 primal, 2 dual
   bool fresh_dual = false; // the dual phase starts with this step: devex weights restart from one
+  bool fresh_primal = false; // primal phase 2 starts with this step: likewise
   for (;;) {
     if (phase == PH_START) {
       Cand r = dev_infeas_row(k, lds, nullptr);
       if (r.idx == 0) {
         phase = PH_PRIMAL2;
+        fresh_primal = true;
       } else {
         Cand pr = dev_price(k, k.T, k.sgn, lds);
         if (pr.idx != 0) {
@@ -408,6 +432,8 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
       if (k.bland && !c->pert_used) {
         // stalled for the first time: perturb instead of pivoting; the next launch prices again
         dev_perturb(k, c);
+        if (fresh_primal)
+          for (int j = TIDX; j <= k.n; j += (int)blockDim.x) k.pw[j] = 1.0;
         if (TIDX == 0) {
           c->step = ST_NONE;
           c->phase = phase;
@@ -415,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
         }
         return;
       }
-      Cand pr = dev_price(k, k.T, k.sgn, lds);
+      Cand pr = dev_price(k, k.T, k.sgn, lds, fresh_primal ? 2 : 1);
       if (pr.idx != 0) {
         q = pr.idx;
         sdir = pr.aux;
@@ -462,6 +488,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
         return;
       }
       phase = PH_PRIMAL2;
+      fresh_primal = true;
     }
   }
   if (c->budget == 0) {
@@ -470,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
     return;
   }
   if (kind == 1) {
-    if (!dev_primal_step(k, c, q, sdir, nullptr, lds)) {
+    if (!dev_primal_step(k, c, q, sdir, nullptr, lds, fresh_primal ? 2 : 1)) {
       if (c->perturbed) dev_restore(k, c);
       dev_finish(c, D_UNBND, phase, rounds);
       return;
@@ -737,34 +764,38 @@ __global__ __launch_bounds__(256) void k_export(Ctl *c, unsigned char *stage, in
 // Every reduction key is a strict total order, so the redundant per-block reductions agree.
 // Arithmetic per entry is identical to k_select/k_update (and to the oracle).
 
-__device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, Cand &x) {
+// devex score of column j: d_j^2 / w (same expression as dev_price modes 1 / 2)
+__device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, double w, Cand &x) {
   if (f == MVX_NS) return false;
   const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
   const bool dn = (f == MVX_NU || f == MVX_NF) && dj < -tol;
   if (!up && !dn) return false;
-  x = Cand{fabs(dj), 0.0, j, up ? 1 : -1};
+  x = Cand{dj * dj / w, 0.0, j, up ? 1 : -1};
   return true;
 }
 
-// bootstrap: price the current objective row into pp[0]; arm the fused path
+// bootstrap: price the current objective row into pp[curA]; arm the fused path
 __global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
   __shared__ Cand lds[17];
-  if (c->done != D_RUN || c->phase != PH_PRIMAL2 || c->stall >= c->stall_limit) { // fused path prices by Dantzig only
+  if (c->done != D_RUN || c->phase != PH_PRIMAL2 || c->stall >= c->stall_limit) { // fused path has no Bland pricing
     if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
     return;
   }
+  // The ping-pong parity stays where the last fused run left it (curA): the current devex weights live in
+  // pw[curA].  The bootstrap k_fb reads side curB = curA^1 and flips curA back to where it is now.
+  const int a = c->curA & 1;
   const int j = (int)blockIdx.x * 256 + TIDX;
   Cand best{0.0, 0.0, 0, 0};
   if (j >= 1 && j <= c->n) {
     Cand x;
-    if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, x)) best = x;
+    if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, c->pw[a][j], x)) best = x;
   }
   best = block_best<0>(best, lds);
-  if (TIDX == 0) c->pp[0][blockIdx.x] = best;
+  if (TIDX == 0) c->pp[a][blockIdx.x] = best;
   if (blockIdx.x == 0 && TIDX == 0) {
     c->fstate = F_RUN;
     c->step = ST_NONE;
-    c->curB = 1;
+    c->curB = a ^ 1;
   }
 }
 
@@ -797,6 +828,8 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
   const Cand *const pp = c->pp[cur];
   Cand *const ppn = c->pp[cur ^ 1];
   const Cand *const rp = c->rp;
+  const double *const pwc = c->pw[cur & 1];
+  double *const pwn = c->pw[(cur & 1) ^ 1];
   const double tol = c->tol_dj, sgn = c->sgn;
   if (done != D_RUN || fstate != F_RUN) return;
   const bool lead = (blockIdx.x == 0 && TIDX == 0);
@@ -813,6 +846,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
     Cand r3 = (lane + 192 < nrb) ? rp[lane + 192] : Cand{0.0, 0.0, 0, 0};
     const double dold_ = act ? T[j] : 0.0;
     const int fj_ = (act && j >= 1) ? nflag[j] : MVX_NS;
+    const double wj_ = (act && j >= 1) ? pwc[j] : 1.0; // primal devex weight of this lane's column
     for (int k = lane + 64; k < npb; k += 64) {
       Cand x = pp[k];
       if (cand_better<0>(x, pc)) pc = x;
@@ -840,6 +874,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
     const int fq = nflag[q];
     const int pr = p ? p : 1;
     const double piv = colq[pr], dq = colq[0];
+    const double wq = pwc[q];
     const double plb = blb[pr], pub = bub[pr];
     const double v = act ? T[(size_t)pr * ldi + j] : 0.0;
     Cand best{0.0, 0.0, 0, 0};
@@ -850,7 +885,8 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
         const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
         if (act && j >= 1) {
           Cand x;
-          if (price_col(j == q ? nf : fj_, sgn * dold_, tol, j, x)) best = x;
+          pwn[j] = wj_; // weights unchanged by a flip; the other set becomes current with k_fb's curA flip
+          if (price_col(j == q ? nf : fj_, sgn * dold_, tol, j, wj_, x)) best = x;
         }
         best = block_best<0>(best, lds);
         if (TIDX == 0) ppn[blockIdx.x] = best;
@@ -878,8 +914,18 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
       const double dnew = (j == q) ? dq / piv : fma(-dq, sj, dold_);
       T[j] = dnew;
       if (j >= 1) {
+        // devex weight update from the scaled pivot row (oracle: primal_step), then the next pricing
+        double wn;
+        if (j == q) {
+          const double cc = wq / (piv * piv);
+          wn = cc > 1.0 ? cc : 1.0;
+        } else {
+          const double cc = sj * sj * wq;
+          wn = cc > wj_ ? cc : wj_;
+        }
+        pwn[j] = wn;
         Cand x;
-        if (price_col(j == q ? lf : fj_, sgn * dnew, tol, j, x)) best = x;
+        if (price_col(j == q ? lf : fj_, sgn * dnew, tol, j, wn, x)) best = x;
       }
     }
     best = block_best<0>(best, lds);

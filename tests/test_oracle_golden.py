@@ -100,7 +100,8 @@ def test_ilp_branch_and_bound_matches_milp(orc, case):
 @pytest.mark.parametrize("case", GOLD["degenerate"], ids=lambda g: g.get("name") or "%dx%d_s%d" % (g["m"], g["n"], g["seed"]))
 def test_stalling_lps_reach_the_optimum(orc, case):
     """Cycling textbook LPs and massively degenerate ones: plain Dantzig pricing spins on them (chvatal,
-    150x150, 200x300, 250x400 never finish); the anti-stalling rules must end on HiGHS's optimum."""
+    150x150, 200x300, 250x400 never finish); devex pricing plus the anti-stalling rules must end on
+    HiGHS's optimum."""
     if "name" in case:
         A, b, c = (np.array(v, float) for v in lpgen.CYCLING[case["name"]])
         P = orc.create()
@@ -113,10 +114,8 @@ def test_stalling_lps_reach_the_optimum(orc, case):
     assert rel(P.obj, case["obj"]) <= RTOL
     x = P.col_prim()
     assert np.all(x >= -1e-9) and np.all(A @ x <= b + 1e-7)
-    if case.get("name") == "chvatal":
-        assert P.pert_cnt == 1  # 64 degenerate pivots, then the perturbation
     if case.get("m", 0) >= 150:
-        assert P.pert_cnt == 1 and P.it_cnt < 20000
+        assert P.pert_cnt == 1 and P.it_cnt < 20000  # the bound perturbation, not luck, gets these out of the vertex
 
 
 @pytest.mark.parametrize("case", GOLD["setcover"], ids=lambda g: "%dx%d_s%d" % (g["m"], g["n"], g["seed"]))
