@@ -2,9 +2,10 @@
 """bench.py -- simplex pivots/s on a dense fp64 tableau, with the HBM roofline of the rank-1
 update kernel and a same-host CPU baseline (BASELINE.json metric).
 
-One "step" = one simplex pivot (k_select + the streamed Gauss-Jordan rank-1 update k_update)
-on the synthetic dense LP of BASELINE.md config 4: m=4096, n=8192, fp64, splitmix64 seed
-12345 (+rank).  The tableau is resident in HBM before the timed region starts.
+One "step" = one simplex pivot (k_fa: selection + pivot row; k_fb: the streamed Gauss-Jordan rank-1
+update) on the synthetic dense LP of BASELINE.md config 4: m=4096, n=8192, fp64, splitmix64 seed
+12345 (+rank).  The tableau is resident in HBM before the timed region starts; a run longer than the
+LP's ~3.4k pivots to optimality carries on with a device-to-device clone of the initial tableau.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -213,12 +214,32 @@ def main():
 
     m, n = args.rows, args.cols
     A, b, c = synth.dense_lp(m, n, args.seed + rank)
-    P = api.create()
-    P.load_dense(A, b, c)
+    P0 = api.create()
+    P0.load_dense(A, b, c)
     del A
-    # warmup: builds the tableau in HBM and runs W untimed pivots
-    rc = P.simplex(it_lim=args.warmup)
-    piv_w = P.it_cnt
+    P0.simplex(it_lim=0)  # builds the tableau in HBM (host build + one upload), no pivots
+    state = {"P": P0.copy(), "device_ms": 0.0}
+
+    def run_pivots(k):
+        """Exactly k pivots of the workload, HBM-resident: when the LP reaches its optimum first (devex pricing
+        needs ~3.4k pivots at 4096x8192) the run carries on with a fresh device-to-device clone of the
+        initial tableau."""
+        left = k
+        state["device_ms"] = 0.0
+        while left > 0:
+            P = state["P"]
+            before = P.it_cnt
+            P.simplex(it_lim=left)
+            state["device_ms"] += api.last_solve_ms(P.h)
+            left -= P.it_cnt - before
+            if left > 0:
+                if P.status != 5:
+                    raise SystemExit("rank %d: LP ended with status %d" % (rank, P.status))
+                state["P"] = P0.copy()
+        return k
+
+    # warmup: W untimed pivots
+    run_pivots(args.warmup)
 
     def barrier():
         if dist is not None:
@@ -227,13 +248,10 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    rc = P.simplex(it_lim=args.steps)
+    steps_done = run_pivots(args.steps)
     barrier()
     el = time.perf_counter() - t0
-    steps_done = P.it_cnt - piv_w
-    if steps_done != args.steps:
-        raise SystemExit("rank %d: LP reached status %d after %d of %d timed pivots -- pick fewer steps" % (rank, P.status, steps_done, args.steps))
-    device_ms = api.last_solve_ms(P.h)
+    device_ms = state["device_ms"]
 
     # max over ranks
     t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -248,13 +266,12 @@ def main():
     if rank == 0:
         api.profile_reset()
         api.profile_enable(1)
-        P.simplex(it_lim=args.profile_steps)
+        pivots = run_pivots(args.profile_steps)
         api.profile_enable(0)
         # events were recorded around every queued launch; only launches that pivoted moved data,
         # the queued-ahead no-op launches after the limit are a few microseconds each
         k_ms = api.profile_update_ms()
         k_n = api.profile_update_launches()
-        pivots = P.it_cnt - piv_w - steps_done
         if pivots > 0 and k_ms > 0:
             avg_ms = k_ms / pivots
             achieved = bytes_per_pivot(m, n) / (avg_ms * 1e-3) / 1e9
