@@ -31,7 +31,7 @@ def assert_same_state(g, o, what=""):
 
 
 @pytest.mark.parametrize("m,n,seed", [(3, 5, 1), (17, 33, 2), (64, 128, 12345), (128, 256, 12345), (100, 37, 5), (256, 512, 12345),
-                                      (512, 1024, 12345), (333, 1500, 8)])
+                                      (512, 1024, 12345), (333, 1500, 8), (1024, 2048, 12345), (1500, 600, 9)])
 def test_dense_lp_bit_exact(gpu, orc, m, n, seed):
     A, b, c = synth.dense_lp(m, n, seed)
     g, o = gpu.create(), orc.create()
