@@ -6,6 +6,7 @@
 //   generateCut3           gmi.cpp:11-117     CutPool::addToPool/addCutConstraint    cut.cpp:6-46
 //   branchAndBound         bs.cpp:54-348      getParentOid / getBranchDirection      bs.cpp:26-52
 // Every LP call goes through `mvx_lp_api`; with the default table that is the gfx950 engine.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -593,11 +594,15 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     std::shared_ptr<MVOLP::NodeData> S2, S3;
     int before2, before3;
   };
+  const bool timing = std::getenv("MVX_BNB_TIMING") != nullptr;
+  double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tC = 0, tD = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   while (!leafContainer.empty() && !stop) {
     if (prm.max_nodes > 0 && count >= prm.max_nodes) {
       hit_limit = 1;
       break;
     }
+    double t0 = now();
     const size_t W = std::min(leafContainer.size(), (size_t)prm.window);
     // A. solve the window (bs.cpp:114-117).  The reference copies the node's problem into the scratch
     // `a` and solves the copy; the node is discarded after this step either way, so its own clone is
@@ -609,6 +614,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       before[w] = api->get_it_cnt(a[w]);
     }
     api->simplex_batch(a.data(), (int)W, nullptr, nullptr);
+    tA += now() - t0; t0 = now();
     // B. replay in queue order
     std::vector<std::vector<mvx_bnb_event>> node_events(W);
     std::vector<Branch> branches;
@@ -625,7 +631,9 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       rec.pivots += api->get_it_cnt(aw) - before[w];
       processed++;
       rec.emit(MVX_EV_PREGNANT, node->oid, api->get_obj_val(aw), 0.0, 0, 0);
+      double ti = now();
       auto ret = printInfo(api, aw, quirks);
+      tB_info += now() - ti;
       const int status = ret.first;
       const std::vector<int> &vars = ret.second;
       if (node->inital) {
@@ -679,7 +687,9 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
         const double bound = api->get_col_prim(aw, pick);
         const int t = api->get_col_type(aw, pick);
         const double l = api->get_col_lb(aw, pick), u = api->get_col_ub(aw, pick);
+        double tc = now();
         br.S2 = std::make_shared<MVOLP::NodeData>(api, aw, id); // even oid (R), then odd (L): bs.cpp:43-52
+        tB_clone += now() - tc;
         br.S3 = std::make_shared<MVOLP::NodeData>(api, aw, id, true);
         node->prob = nullptr;
         rec.node(br.S2->oid, node->oid);
@@ -710,6 +720,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       }
       count++;
     }
+    tB += now() - t0; t0 = now();
     // C. every child of this round is an independent LP (bs.cpp:279,287): one batched solve
     std::vector<void *> kids;
     for (auto &br : branches) {
@@ -717,6 +728,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       kids.push_back(br.S3->prob);
     }
     if (!kids.empty()) api->simplex_batch(kids.data(), (int)kids.size(), nullptr, nullptr);
+    tC += now() - t0; t0 = now();
     for (auto &br : branches) {
       rec.pivots += (api->get_it_cnt(br.S2->prob) - br.before2) + (api->get_it_cnt(br.S3->prob) - br.before3);
       br.S2->upperBound = api->get_obj_val(br.S2->prob);
@@ -732,7 +744,9 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     rec.sink = nullptr;
     for (size_t w = 0; w < W; w++) rec.events.insert(rec.events.end(), node_events[w].begin(), node_events[w].end());
     leafContainer.erase(leafContainer.begin(), leafContainer.begin() + (long)processed);
+    tD += now() - t0;
   }
+  if (timing) std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f)  C %.1f ms  D %.1f ms\n", tA * 1e3, tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tC * 1e3, tD * 1e3);
   leafContainer.clear();
   pack_result(res, rec, id, count, has_incumbent, bestLower, incumbent_oid, n0, xbest, hit_limit);
   return 0;

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <tuple>
+#include <unordered_set>
 #include <vector>
 
 #include "engine.hpp"
@@ -83,6 +84,10 @@ struct Context {
   // slab recycling (B&B clones come and go at one size)
   std::multimap<size_t, void *> free_slabs;
   size_t cached_bytes = 0;
+  // slabs carved out of one multi-slab allocation (a growing B&B tree asks for one slab per open node:
+  // hipMalloc costs ~60 us a call, a chunk of 32 amortises it).  They are recycled through free_slabs
+  // like any other slab but never hipFree'd one by one.
+  std::unordered_set<void *> arena_slabs;
   // profiling (main context only)
   bool prof = false;
   double prof_update_ms = 0.0;
@@ -246,20 +251,55 @@ static void *slab_alloc(Context &c, size_t bytes) {
   if (it != c.free_slabs.end()) {
     void *p = it->second;
     c.free_slabs.erase(it);
-    c.cached_bytes -= bytes;
+    if (!c.arena_slabs.count(p)) c.cached_bytes -= bytes;
     return p;
   }
   void *p = nullptr;
+  if (bytes <= ((size_t)64 << 20)) {
+    const size_t count = std::min<size_t>(32, std::max<size_t>(2, ((size_t)256 << 20) / bytes));
+    if (hipMalloc(&p, bytes * count) == hipSuccess) {
+      for (size_t k = 0; k < count; k++) {
+        void *q = (unsigned char *)p + k * bytes;
+        c.arena_slabs.insert(q);
+        if (k) c.free_slabs.emplace(bytes, q);
+      }
+      return p;
+    }
+    (void)hipGetLastError();
+    p = nullptr;
+  }
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
-    // drop the cache and retry once
+    // drop the cache (what can be freed of it) and retry once
     sync_stream();
-    for (auto &kv : c.free_slabs) (void)hipFree(kv.second);
-    c.free_slabs.clear();
-    c.cached_bytes = 0;
+    for (auto it2 = c.free_slabs.begin(); it2 != c.free_slabs.end();) {
+      if (c.arena_slabs.count(it2->second)) {
+        ++it2;
+        continue;
+      }
+      (void)hipFree(it2->second);
+      c.cached_bytes -= it2->first;
+      it2 = c.free_slabs.erase(it2);
+    }
     HIPCHECK(hipMalloc(&p, bytes));
   }
   return p;
+}
+
+// back to the cache; `may_free`: release it to the driver instead when the cache is full
+static void slab_recycle(Context &c, SolveCtx &sc, void *slab, size_t bytes) {
+  if (c.arena_slabs.count(slab)) {
+    c.free_slabs.emplace(bytes, slab);
+    return;
+  }
+  const size_t cache_limit = (size_t)8 << 30;
+  if (c.cached_bytes + bytes <= cache_limit) {
+    c.free_slabs.emplace(bytes, slab);
+    c.cached_bytes += bytes;
+  } else {
+    HIPCHECK(hipStreamSynchronize(sc.stream));
+    HIPCHECK(hipFree(slab));
+  }
 }
 
 void release_device(mvx_prob *P) {
@@ -268,14 +308,7 @@ void release_device(mvx_prob *P) {
   SolveCtx &sc = c.main;
   (void)sc;
   // the stream is in-order: work already queued on the slab finishes before any reuse
-  const size_t cache_limit = (size_t)8 << 30;
-  if (c.cached_bytes + P->slab_bytes <= cache_limit) {
-    c.free_slabs.emplace(P->slab_bytes, P->slab);
-    c.cached_bytes += P->slab_bytes;
-  } else {
-    HIPCHECK(hipStreamSynchronize(sc.stream));
-    HIPCHECK(hipFree(P->slab));
-  }
+  slab_recycle(c, sc, P->slab, P->slab_bytes);
   P->slab = nullptr;
   P->slab_bytes = 0;
   P->d_T = nullptr;
@@ -317,8 +350,7 @@ static void grow_rows(mvx_prob *P, int m_new) {
   HIPCHECK(hipMemcpyAsync(P->d_nlb, onlb, (size_t)ld * 8, hipMemcpyDeviceToDevice, sc.stream));
   HIPCHECK(hipMemcpyAsync(P->d_nub, onub, (size_t)ld * 8, hipMemcpyDeviceToDevice, sc.stream));
   // recycle the old slab (in-order stream: the copies above complete before any reuse)
-  c.free_slabs.emplace(o_bytes, o_slab);
-  c.cached_bytes += o_bytes;
+  slab_recycle(c, sc, o_slab, o_bytes);
 }
 
 // --------------------------------------------------------------------------- helpers
@@ -1122,11 +1154,18 @@ void engine_copy(mvx_prob *dst, const mvx_prob *src) {
   (void)sc;
   void *slab = slab_alloc(c, src->slab_bytes);
   bind_slab(dst, slab, src->m_cap, src->ld);
-  // only the live rows of T need to travel; the small arrays follow T in one contiguous tail
+  // only the live rows of T need to travel; the small arrays follow T in one contiguous tail.  When the
+  // spare rows in between are few (B&B clones of a small tableau) one call over the whole slab is cheaper
+  // than two: the host side of a copy call costs more than the extra bytes
   SlabLayout L = slab_layout(src->m_cap, src->ld);
-  HIPCHECK(hipMemcpyAsync(dst->d_T, src->d_T, (size_t)(src->m + 1) * src->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
-  HIPCHECK(hipMemcpyAsync((unsigned char *)slab + L.o_bvar, (const unsigned char *)src->slab + L.o_bvar, L.total - L.o_bvar,
-                          hipMemcpyDeviceToDevice, sc.stream));
+  const size_t live = (size_t)(src->m + 1) * src->ld * 8;
+  if (L.o_bvar - live <= (size_t)1 << 20) {
+    HIPCHECK(hipMemcpyAsync(slab, src->slab, L.total, hipMemcpyDeviceToDevice, sc.stream));
+  } else {
+    HIPCHECK(hipMemcpyAsync(dst->d_T, src->d_T, live, hipMemcpyDeviceToDevice, sc.stream));
+    HIPCHECK(hipMemcpyAsync((unsigned char *)slab + L.o_bvar, (const unsigned char *)src->slab + L.o_bvar, L.total - L.o_bvar,
+                            hipMemcpyDeviceToDevice, sc.stream));
+  }
   dst->valid = true;
 }
 
