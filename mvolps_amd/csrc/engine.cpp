@@ -37,6 +37,7 @@ void launch_select(Ctl *, hipStream_t, int slots = 1);
 void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1);
 void launch_p1_head(Ctl *, hipStream_t);
 void launch_p1_select(Ctl *, hipStream_t);
+void launch_p1_fix(Ctl *, int n, hipStream_t);
 void launch_rowcomb(Ctl *, int m, int n, int respect_done, hipStream_t);
 void launch_shift_nonbasic(double *T, int ld, int m, int jj, double delta, hipStream_t);
 void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub, hipStream_t);
@@ -61,6 +62,7 @@ struct SolveCtx {
   int *d_gflag = nullptr;
   double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
   double *d_dw = nullptr; // dual devex weights by row
+  int *d_p1list = nullptr; // phase 1: rows whose infeasibility sign changed
   double *d_pw[2] = {nullptr, nullptr}; // primal devex weights by column, two sets (fused path ping-pong)
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
@@ -175,6 +177,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
   size_t o_olb = carve((size_t)(mc + l + 1) * 8), o_oub = carve((size_t)(mc + l + 1) * 8);
   size_t o_dw = carve((size_t)(mc + 1) * 8);
+  size_t o_p1l = carve((size_t)(mc + 2) * 4);
   size_t o_pw0 = carve((size_t)l * 8), o_pw1 = carve((size_t)l * 8);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
@@ -196,6 +199,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_olb = (double *)(b + o_olb);
   sc.d_oub = (double *)(b + o_oub);
   sc.d_dw = (double *)(b + o_dw);
+  sc.d_p1list = (int *)(b + o_p1l);
   sc.d_pw[0] = (double *)(b + o_pw0);
   sc.d_pw[1] = (double *)(b + o_pw1);
   sc.stage_bytes = stage_size(mc, l);
@@ -403,6 +407,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->olb = sc.d_olb; h->oub = sc.d_oub; h->dw = sc.d_dw;
   h->pw[0] = sc.d_pw[0]; h->pw[1] = sc.d_pw[1];
+  h->p1_list = sc.d_p1list;
   h->colqx[0] = sc.d_colqx[0]; h->colqx[1] = sc.d_colqx[1];
   h->betac[0] = sc.d_betac[0]; h->betac[1] = sc.d_betac[1];
   h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
@@ -590,12 +595,13 @@ static void job_enqueue(Context &c, SolveJob &J) {
     return;
   }
   if (J.mode == SolveJob::PHASE1) {
-    // host-driven phase 1: per iteration head -> cost row (rowcomb) -> select -> update
+    // host-driven phase 1: per iteration head (signs, changed rows) -> cost-row fix -> select -> update;
+    // the cost row is tableau row m+1, so the update grid reaches one row further
     for (int k = 0; k < J.pb; k++) {
       launch_p1_head(sc.d_ctl, sc.stream);
-      launch_rowcomb(sc.d_ctl, m, n, 1, sc.stream);
+      launch_p1_fix(sc.d_ctl, n, sc.stream);
       launch_p1_select(sc.d_ctl, sc.stream);
-      launch_update(sc.d_ctl, m, n, sc.stream);
+      launch_update(sc.d_ctl, m + 1, n, sc.stream);
     }
     launch_export(sc.d_ctl, sc.d_stage, m, n, 0, sc.stream);
     stage_copy_async(sc, P);
@@ -759,8 +765,8 @@ static bool job_collect(Context &c, SolveJob &J) {
   if (J.done == D_NEED_PHASE1) {
     snap.done = D_RUN;
     snap.phase = PH_PHASE1;
-    snap.rc_base = nullptr;
-    snap.rc_out = sc.d_cost1;
+    snap.p1_init = 1; // k_p1_head zeroes the cost row (tableau row m+1) and the signs
+    snap.p1_fix_q = 0;
     *sc.h_ctl = snap;
     upload_ctl(sc);
     J.mode = SolveJob::PHASE1;

@@ -541,28 +541,78 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
 }
 
 // ------------------------------------------------------------------------ phase-1 kernels
+// Phase 1 keeps its cost row  sum_i g[i]*T[i][:]  (g = +1 below the lower bound, -1 above the upper one) in
+// tableau row m+1 and carries it through the pivots (k_update treats it like any other row) instead of
+// recomputing it: k_p1_head lists, in ascending order, the rows whose sign changed since the last
+// iteration, k_p1_fix adds them with the signed difference (oracle: primal_phase1).
 __global__ __launch_bounds__(1024) void k_p1_head(Ctl *c) {
-  __shared__ int s_cnt[16];
+  __shared__ int s_scan[1024];
+  __shared__ int s_inf[16];
   if (c->done != D_RUN) return;
+  const int m = c->m, n = c->n, bs = (int)blockDim.x;
   const size_t ld = (size_t)c->ld;
   const double tol = c->tol_bnd;
-  int cnt = 0;
-  for (int i = 1 + TIDX; i <= c->m; i += (int)blockDim.x) {
+  double *cost = c->T + (size_t)(m + 1) * ld;
+  const int init = c->p1_init;
+  if (init) {
+    for (int j = TIDX; j <= n; j += bs) cost[j] = 0.0;
+    for (int i = TIDX; i <= m + 1; i += bs) c->gflag[i] = 0;
+  } else if (TIDX == 0 && c->p1_fix_q) {
+    // the last pivot left g[p]*e_q in the row: the leaving variable now sits on the bound it violated
+    cost[c->p1_fix_q] = cost[c->p1_fix_q] - (double)c->p1_fix_g;
+  }
+  __syncthreads();
+  // this lane's rows: a contiguous chunk, so that the list comes out in ascending row order
+  const int R = (m + bs - 1) / bs;
+  const int i0 = 1 + TIDX * R;
+  int nchg = 0, ninf = 0;
+  for (int r = 0; r < R; r++) {
+    const int i = i0 + r;
+    if (i > m) break;
     const double beta = c->T[(size_t)i * ld];
     const double lb = c->blb[i], ub = c->bub[i];
     int g = 0;
     if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) g = 1;
     if (ub < INFINITY && beta > ub + tol * (1.0 + fabs(ub))) g = -1;
-    c->gflag[i] = g;
-    c->wts[i] = (double)g;
-    cnt += (g != 0);
+    nchg += (g != c->gflag[i]);
+    ninf += (g != 0);
   }
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-  if ((TIDX & 63) == 0) s_cnt[TIDX >> 6] = cnt;
+  // exclusive scan of the change counts over the lanes (Hillis-Steele in LDS)
+  s_scan[TIDX] = nchg;
+  __syncthreads();
+  for (int off = 1; off < bs; off <<= 1) {
+    const int v = (TIDX >= off) ? s_scan[TIDX - off] : 0;
+    __syncthreads();
+    s_scan[TIDX] += v;
+    __syncthreads();
+  }
+  int pos = s_scan[TIDX] - nchg;
+  const int total = s_scan[bs - 1];
+  for (int r = 0; r < R; r++) {
+    const int i = i0 + r;
+    if (i > m) break;
+    const double beta = c->T[(size_t)i * ld];
+    const double lb = c->blb[i], ub = c->bub[i];
+    int g = 0;
+    if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) g = 1;
+    if (ub < INFINITY && beta > ub + tol * (1.0 + fabs(ub))) g = -1;
+    const int go = c->gflag[i];
+    if (g != go) {
+      c->p1_list[pos] = i;
+      c->wts[pos] = (double)(g - go);
+      pos++;
+      c->gflag[i] = g;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) ninf += __shfl_down(ninf, off, 64);
+  if ((TIDX & 63) == 0) s_inf[TIDX >> 6] = ninf;
   __syncthreads();
   if (TIDX == 0) {
     int tot = 0;
-    for (int w = 0; w < ((int)blockDim.x >> 6); w++) tot += s_cnt[w];
+    for (int w = 0; w < (bs >> 6); w++) tot += s_inf[w];
+    c->p1_nchg = total;
+    c->p1_init = 0;
+    c->p1_fix_q = 0;
     if (tot == 0) {
       c->done = D_PFEAS;
       c->step = ST_NONE;
@@ -570,11 +620,41 @@ __global__ __launch_bounds__(1024) void k_p1_head(Ctl *c) {
   }
 }
 
+// cost[j] = fma(d_k, T[i_k][j], cost[j]) over the listed rows, in list order; one lane per column
+__global__ __launch_bounds__(256) void k_p1_fix(Ctl *c) {
+  if (c->done != D_RUN) return;
+  const int nchg = c->p1_nchg;
+  if (nchg == 0) return;
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  if (j > c->n) return;
+  const size_t ld = (size_t)c->ld;
+  const double *T = c->T;
+  double *cost = c->T + (size_t)(c->m + 1) * ld;
+  const int *list = c->p1_list;
+  const double *dv = c->wts;
+  double v = cost[j];
+  constexpr int U = 8;
+  int k = 0;
+  for (; k + U <= nchg; k += U) {
+    double t[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      t[u] = T[(size_t)list[k + u] * ld + j];
+      d[u] = dv[k + u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) v = fma(d[u], t[u], v);
+  }
+  for (; k < nchg; k++) v = fma(dv[k], T[(size_t)list[k] * ld + j], v);
+  cost[j] = v;
+}
+
 __global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
   __shared__ Cand lds[17];
   const KC k = load_kc(c);
   if (c->done != D_RUN) return;
-  Cand pr = dev_price(k, c->cost1, 1.0, lds);
+  const double *cost = k.T + (size_t)(k.m + 1) * k.ld;
+  Cand pr = dev_price(k, cost, 1.0, lds);
   if (pr.idx == 0) {
     dev_finish(c, D_NOFEAS, PH_PHASE1, c->rounds);
     return;
@@ -583,7 +663,18 @@ __global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
     dev_finish(c, D_ITLIM, PH_PHASE1, c->rounds);
     return;
   }
-  if (!dev_primal_step(k, c, pr.idx, pr.aux, c->gflag, lds)) dev_finish(c, D_FAIL, PH_PHASE1, c->rounds);
+  if (!dev_primal_step(k, c, pr.idx, pr.aux, c->gflag, lds)) {
+    dev_finish(c, D_FAIL, PH_PHASE1, c->rounds);
+    return;
+  }
+  if (TIDX == 0 && c->step == ST_PIVOT) {
+    // the cost row rides along as row m+1 of the update; its leaving-variable term is dropped by the next head
+    const int p = c->p, q = c->q;
+    k.colq[k.m + 1] = cost[q];
+    c->p1_fix_q = q;
+    c->p1_fix_g = c->gflag[p];
+    c->gflag[p] = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------- k_update
@@ -617,7 +708,7 @@ __global__ __launch_bounds__(256) void k_update(Ctl *c) {
   const int i0 = (int)blockIdx.y * TR;
   // a batched launch is sized for its largest slot: blocks wholly outside this slot's tableau leave;
   // a block that straddles row m streams on into the spare rows every slab keeps behind it (ROW_SPARE)
-  if (j0 > n || i0 > m) return;
+  if (j0 > n || i0 > m + (c->phase == PH_PHASE1 ? 1 : 0)) return; // phase 1: row m+1 is its cost row
   const double2 s = *reinterpret_cast<const double2 *>(c->srow + j0);
   const bool q0 = (j0 == q), q1 = (j0 + 1 == q);
   double *base = c->T + (size_t)i0 * ld + j0;
@@ -1185,6 +1276,7 @@ void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
 }
 void launch_p1_head(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_head, dim3(1), dim3(1024), 0, s, d_ctl); }
 void launch_p1_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_select, dim3(1), dim3(1024), 0, s, d_ctl); }
+void launch_p1_fix(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_p1_fix, dim3((n + 1 + 255) / 256), dim3(256), 0, s, d_ctl); }
 void launch_rowcomb(Ctl *d_ctl, int m, int n, int respect_done, hipStream_t s) {
   const int nchunks = (m + ROWCOMB_CHUNK - 1) / ROWCOMB_CHUNK;
   dim3 grid((n + 1 + 255) / 256, nchunks > 0 ? nchunks : 1);

@@ -78,6 +78,10 @@ struct Ctl {
   // variable number, saved when the perturbation is applied
   double *olb, *oub;
   int perturbed, pert_used, n_pert;
+  // primal phase 1: the infeasibility-sum cost row lives in tableau row m+1 (first spare row) and is carried
+  // through the pivots by k_update; k_p1_head lists the rows whose sign changed (p1_list / wts), k_p1_fix adds them
+  int *p1_list;
+  int p1_init, p1_nchg, p1_fix_q, p1_fix_g;
   double *pw[2]; // [ld] primal devex reference weights by non-basic position (oracle: ctl_t.pw); the current set
                  // is pw[curA]: the fused path writes the other one and k_fb flips curA, the generic path updates in place
   double *dw; // [m_cap+1] dual devex reference weights by row (oracle: dual_simplex's w), reset on entering the dual phase

@@ -534,6 +534,10 @@ typedef struct {
      pw[q] = max(pw[q] / a_pq^2, 1).  Reset on entering the phase.  Halves the pivots of large LPs
      (1024x2048 seed 12345: 1439 -> 754) */
   double *pw;
+  /* primal phase 1 only: the infeasibility-sum cost row sum_i g[i]*T[i][:] is carried through the pivots
+     like one more tableau row (xrow) instead of being recomputed; xg = the signs g it is built from */
+  double *xrow;
+  int *xg;
 } ctl_t;
 
 #define PERT_EPS 1e-6
@@ -602,7 +606,7 @@ static int select_infeasible_row(const orc_prob *P, double tol_bnd, int *to_uppe
 
 /* Gauss-Jordan pivot on (p,q).  bound = value the leaving variable lands on,
    leave_flag = its non-basic status afterwards. */
-static void pivot(orc_prob *P, int p, int q, double bound, int leave_flag) {
+static void pivot(orc_prob *P, int p, int q, double bound, int leave_flag, double *xrow) {
   int m = P->m, n = P->n, ld = P->ld;
   double *rowp = &TT(P, p, 0);
   double piv = rowp[q];
@@ -618,6 +622,12 @@ static void pivot(orc_prob *P, int p, int q, double bound, int leave_flag) {
     double nci = -ci;
     for (int j = 0; j <= n; j++) row[j] = fma(nci, s[j], row[j]);
     row[q] = ci / piv;
+  }
+  if (xrow) { /* one more row i != p (the device keeps it in tableau row m+1) */
+    double ci = xrow[q];
+    double nci = -ci;
+    for (int j = 0; j <= n; j++) xrow[j] = fma(nci, s[j], xrow[j]);
+    xrow[q] = ci / piv;
   }
   for (int j = 1; j <= n; j++) rowp[j] = -s[j];
   rowp[q] = 1.0 / piv;
@@ -709,7 +719,13 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
     double c = wq / (apq * apq);
     w[q] = c > 1.0 ? c : 1.0;
   }
-  pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], p_up));
+  pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], p_up), ctl->xrow);
+  if (ctl->xrow) {
+    /* xrow is now sum_{i != p} g[i]*T'[i][:] + g[p]*e_q: the leaving variable sits on the bound it was
+       violating (or was feasible, g[p] = 0), so its term goes; row p holds the entering variable, no term yet */
+    ctl->xrow[q] = ctl->xrow[q] - (double)ctl->xg[p];
+    ctl->xg[p] = 0;
+  }
   if (ctl->budget > 0) ctl->budget--;
   if (bland) P->bland_cnt++;
   ctl->stall = (bt <= DEGEN_TOL) ? ctl->stall + 1 : 0;
@@ -791,24 +807,32 @@ static int primal_phase2(orc_prob *P, ctl_t *ctl) {
   }
 }
 
+/* Primal phase 1: minimise the sum of infeasibilities.  The cost row sum_i g[i]*T[i][:] (g = +1 below the
+   lower bound, -1 above the upper one) is kept up to date instead of recomputed: rows whose sign changed
+   since the last iteration are added / removed in ascending row order, the pivot carries the row along. */
 static int primal_phase1(orc_prob *P, ctl_t *ctl) {
   int m = P->m, n = P->n;
-  int *g = (int *)xcalloc((size_t)m + 1, sizeof(int));
-  double *w = (double *)xcalloc((size_t)m + 1, sizeof(double));
+  int *g = (int *)xcalloc((size_t)m + 2, sizeof(int));
   double *cost = (double *)xcalloc((size_t)n + 1, sizeof(double));
   int ret;
+  ctl->xrow = cost;
+  ctl->xg = g;
   for (;;) {
     int ninf = 0;
     for (int i = 1; i <= m; i++) {
       double beta = TT(P, i, 0), lb = P->blb[i], ub = P->bub[i];
-      g[i] = 0;
-      if (lb > -INF && beta < lb - ctl->tol_bnd * (1.0 + fabs(lb))) g[i] = 1;
-      if (ub < INF && beta > ub + ctl->tol_bnd * (1.0 + fabs(ub))) g[i] = -1;
-      w[i] = (double)g[i];
-      if (g[i]) ninf++;
+      int gn = 0;
+      if (lb > -INF && beta < lb - ctl->tol_bnd * (1.0 + fabs(lb))) gn = 1;
+      if (ub < INF && beta > ub + ctl->tol_bnd * (1.0 + fabs(ub))) gn = -1;
+      if (gn != g[i]) {
+        const double d = (double)(gn - g[i]);
+        const double *row = &TT(P, i, 0);
+        for (int j = 0; j <= n; j++) cost[j] = fma(d, row[j], cost[j]);
+        g[i] = gn;
+      }
+      if (gn) ninf++;
     }
     if (ninf == 0) { ret = R_PFEAS; break; }
-    rowcomb(P, w, NULL, cost);
     int sdir = 0;
     int q = price(P, cost, 1.0, ctl->tol_dj, &sdir, bland_on(ctl), NULL);
     if (q == 0) { ret = R_NOFEAS; break; }
@@ -816,7 +840,9 @@ static int primal_phase1(orc_prob *P, ctl_t *ctl) {
     int r = primal_step(P, ctl, q, sdir, g);
     if (r == R_UNBND) { ret = R_FAIL; break; }
   }
-  free(g); free(w); free(cost);
+  ctl->xrow = NULL;
+  ctl->xg = NULL;
+  free(g); free(cost);
   return ret;
 }
 
@@ -874,7 +900,7 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
       w[p] = c > 1.0 ? c : 1.0;
     }
     double bound = to_upper ? P->bub[p] : P->blb[p];
-    pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], to_upper));
+    pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], to_upper), NULL);
     if (ctl->budget > 0) ctl->budget--;
     if (bland) P->bland_cnt++;
     ctl->stall = (br <= DEGEN_TOL) ? ctl->stall + 1 : 0;
@@ -907,7 +933,7 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
      must end with EITLIM rather than spin).  Same formula in the HIP engine. */
   int budget = parm->it_lim >= 0 ? parm->it_lim : 200 * (P->m + P->n) + 100000;
   int stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
-  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, budget, 0, stall_limit, 0, 0, NULL};
+  ctl_t ctl = {parm->tol_bnd, parm->tol_dj, parm->tol_piv, budget, 0, stall_limit, 0, 0, NULL, NULL, NULL};
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
   for (int round = 0; round < 64; round++) {
     int to_upper = 0, sdir = 0;
