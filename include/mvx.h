@@ -160,9 +160,6 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf);
 /* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
    for measurement sweeps -- results are identical for every setting */
 void mvx_set_tuning(int tr, int hot, int nt);
-/* replay each batch of queued pivots as one captured hipGraph instead of eager launches (default
-   off: measured no gain on MI355X -- small-kernel dispatch is command-processor-bound) */
-void mvx_use_graphs(int on);
 /* number of handles that share one launch in mvx_simplex_batch (default 64, 2..256) */
 void mvx_set_batch_slots(int slots);
 /* block until all work queued on the engine stream has finished */

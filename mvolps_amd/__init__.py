@@ -22,7 +22,6 @@ _EXTRA = {
     "last_solve_ms": (C.c_double, [C.c_void_p]),
     "sync": (None, []),
     "set_tuning": (None, [C.c_int, C.c_int, C.c_int]),
-    "use_graphs": (None, [C.c_int]),
     "set_batch_slots": (None, [C.c_int]),
     "simplex_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "pack_size": (C.c_longlong, [C.c_void_p]),

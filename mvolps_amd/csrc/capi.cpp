@@ -420,7 +420,6 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
   return mvx::engine_unpack(dst, dev_buf);
 }
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
-void mvx_use_graphs(int on) { mvx::use_graphs(on); }
 void mvx_set_stall_limit(int limit) { mvx::set_stall_limit(limit); }
 void mvx_set_batch_slots(int slots) { mvx::set_batch_slots(slots); }
 void mvx_profile_enable(int on) { mvx::profile_enable(on); }

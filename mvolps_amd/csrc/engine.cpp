@@ -69,15 +69,6 @@ struct SolveCtx {
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
   size_t stage_bytes = 0;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
-  // captured launch sequences: kernels take only Ctl*, so one hipGraph per (grid geometry, depth)
-  // serves every handle that runs on this context
-  struct GraphKey {
-    int kind, m_grid, n, depth, m_cap, ld;
-    bool operator<(const GraphKey &o) const {
-      return std::tie(kind, m_grid, n, depth, m_cap, ld) < std::tie(o.kind, o.m_grid, o.n, o.depth, o.m_cap, o.ld);
-    }
-  };
-  std::map<GraphKey, hipGraphExec_t> graphs;
 };
 
 struct Context {
@@ -99,7 +90,6 @@ struct Context {
 
 static Context *g_ctx = nullptr;
 static int g_stall_limit = 0;      // > 0: overrides 64 + (m+n)/8 (tests drive the anti-stalling rules with it)
-static bool g_use_graphs = false; // measured: no gain (dispatch is command-processor-bound, not host-bound)
 static int g_requested_dev = -1;
 
 int device_count() {
@@ -155,9 +145,6 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   HIPCHECK(hipStreamSynchronize(sc.stream));
   int mc = m_cap > sc.sc_m_cap ? m_cap : sc.sc_m_cap;
   int l = ld > sc.sc_ld ? ld : sc.sc_ld;
-  // captured graphs hold the staging pointers: drop them with the buffers
-  for (auto &kv : sc.graphs) HIPCHECK(hipGraphExecDestroy(kv.second));
-  sc.graphs.clear();
   if (sc.scratch) HIPCHECK(hipFree(sc.scratch));
   if (sc.d_stage) HIPCHECK(hipFree(sc.d_stage));
   if (sc.h_stage) HIPCHECK(hipHostFree(sc.h_stage));
@@ -619,19 +606,11 @@ static void job_enqueue(Context &c, SolveJob &J) {
   auto ev = [&]() {
     if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[J.ev_used++], sc.stream));
   };
-  // The whole batch (launches + export + staging copy) is one hipGraph replay unless per-kernel
-  // events are wanted: eager launches cost the host ~3.5 us each, which bounds small tableaux and
-  // concurrent node solves; a replay is one call.
-  const bool use_graph = g_use_graphs && !J.profiled;
+  // (replaying each batch as one captured hipGraph was measured: no gain -- the dispatch of small kernels is
+  // bound by the command processor, not by the host -- and removed)
   int depth;
-  SolveCtx::GraphKey key;
-  if (J.try_fused) {
-    depth = std::max(0, std::min(batch - 1, remaining - 1));
-    key = {1, m, n, depth, P->m_cap, P->ld};
-  } else {
-    depth = std::max(1, std::min(batch, remaining));
-    key = {0, P->m_cap, n, depth, P->m_cap, P->ld};
-  }
+  if (J.try_fused) depth = std::max(0, std::min(batch - 1, remaining - 1));
+  else depth = std::max(1, std::min(batch, remaining));
   auto body = [&](int m_grid) {
     if (J.try_fused) {
       // one generic step settles the phase; if it is primal phase 2 the fused two-kernel pipeline
@@ -661,26 +640,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
     launch_export(sc.d_ctl, sc.d_stage, m_grid, n, 0, sc.stream);
     stage_copy_async(sc, P);
   };
-  if (!use_graph) {
-    body(m);
-    return;
-  }
-  auto it = sc.graphs.find(key);
-  if (it == sc.graphs.end()) {
-    if (sc.graphs.size() >= 64) { // bounded cache: drop everything, shapes have moved on
-      for (auto &kv : sc.graphs) HIPCHECK(hipGraphExecDestroy(kv.second));
-      sc.graphs.clear();
-    }
-    hipGraph_t g = nullptr;
-    hipGraphExec_t ge = nullptr;
-    HIPCHECK(hipStreamBeginCapture(sc.stream, hipStreamCaptureModeRelaxed));
-    body(key.m_grid);
-    HIPCHECK(hipStreamEndCapture(sc.stream, &g));
-    HIPCHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    HIPCHECK(hipGraphDestroy(g));
-    it = sc.graphs.emplace(key, ge).first;
-  }
-  HIPCHECK(hipGraphLaunch(it->second, sc.stream));
+  body(m);
 }
 
 // The staging buffer holds the control block and, because the solve has ended (k_export packs the
@@ -1327,7 +1287,6 @@ void tuning(int tr, int hot, int nt) {
   }
 }
 
-void use_graphs(int on) { g_use_graphs = on != 0; }
 void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }
 void profile_enable(int on) { ctx().prof = on != 0; }

@@ -31,7 +31,6 @@ long long engine_pack_size(const mvx_prob *P);
 int engine_pack(const mvx_prob *P, void *dev_buf);
 int engine_unpack(mvx_prob *dst, const void *dev_buf);
 void tuning(int tr, int hot, int nt);
-void use_graphs(int on);
 void set_stall_limit(int limit);
 void set_batch_slots(int k);
 void profile_enable(int on);

@@ -23,9 +23,8 @@ def children(k):
         out.append(ch)
     return out
 
-# warm the stream pool and the graph caches so that steady-state throughput is what is printed
+# warm up so that steady-state throughput is what is printed
 for g in (1, 0):
-    api.use_graphs(g)
     kids = children(16)
     api.simplex_batch((C.c_void_p * 16)(*[k.h for k in kids]), 16, None, None)
     for ch in children(2):

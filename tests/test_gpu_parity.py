@@ -432,3 +432,4 @@ def test_bland_fallback_bit_exact(gpu, orc, limit):
     finally:
         gpu.set_stall_limit(0)
         orc.set_stall_limit(0)
+
