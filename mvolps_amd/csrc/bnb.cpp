@@ -11,8 +11,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <future>
 #include <limits>
 #include <memory>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -242,6 +244,7 @@ struct NodeData { // util.h:35-54
   void *prob;
   bool inital;
   int oid;
+  int repiv = -1; // window driver: pivots of the pop-time re-solve (bs.cpp:117) when it was done ahead, else -1
 
 private:
   const mvx_lp_api *_api;
@@ -594,9 +597,51 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     std::shared_ptr<MVOLP::NodeData> S2, S3;
     int before2, before3;
   };
+  // One round of the loop.  Its child solves (phase C) run on a worker thread while the main thread replays
+  // the next window, whose nodes were solved rounds ago: a breadth-first queue is longer than the window
+  // almost all the time.  Results do not depend on the overlap -- every LP is solved by the same calls on the
+  // same state -- and the event stream is flushed round by round, in order.
+  struct Round {
+    std::vector<std::vector<mvx_bnb_event>> node_events;
+    std::vector<Branch> branches;
+    std::vector<void *> kids;
+    std::vector<int> after1, repiv; // per kid: pivot count after its first solve; pivots of the re-solve done ahead (-1: none)
+    std::vector<double> obj1;       // per kid: objective after its first solve (bs.cpp:280,288)
+    std::future<void> fut;
+    bool active = false;
+  };
+  Round pend;
+  std::unordered_set<const void *> inflight;
   const bool timing = std::getenv("MVX_BNB_TIMING") != nullptr;
-  double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tC = 0, tD = 0;
+  double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tWait = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+  // wait for a round's children, book their results, flush the round's events
+  auto finalize = [&](Round &R) {
+    if (!R.active) return;
+    const double t0 = now();
+    if (R.fut.valid()) R.fut.get();
+    tWait += now() - t0;
+    for (size_t b = 0; b < R.branches.size(); b++) {
+      Branch &br = R.branches[b];
+      const size_t k2 = 2 * b, k3 = 2 * b + 1;
+      rec.pivots += (R.after1[k2] - br.before2) + (R.after1[k3] - br.before3);
+      br.S2->upperBound = R.obj1[k2];
+      br.S3->upperBound = R.obj1[k3];
+      br.S2->repiv = R.repiv[k2];
+      br.S3->repiv = R.repiv[k3];
+      rec.bound[(size_t)br.S2->oid] = br.S2->upperBound;
+      rec.bound[(size_t)br.S3->oid] = br.S3->upperBound;
+      rec.sink = &R.node_events[br.slot];
+      rec.emit(MVX_EV_CANDIDATE, br.S2->oid, br.S2->upperBound, 0.0, 0, 0);
+      rec.emit(MVX_EV_CANDIDATE, br.S3->oid, br.S3->upperBound, 0.0, 0, 0);
+    }
+    rec.sink = nullptr;
+    for (auto &ne : R.node_events) rec.events.insert(rec.events.end(), ne.begin(), ne.end());
+    inflight.clear();
+    R = Round();
+  };
+
   while (!leafContainer.empty() && !stop) {
     if (prm.max_nodes > 0 && count >= prm.max_nodes) {
       hit_limit = 1;
@@ -604,20 +649,34 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     }
     double t0 = now();
     const size_t W = std::min(leafContainer.size(), (size_t)prm.window);
+    // the window may reach into the children that are still being solved
+    for (size_t w = 0; w < W; w++)
+      if (inflight.count(leafContainer[w]->prob)) {
+        finalize(pend);
+        break;
+      }
     // A. solve the window (bs.cpp:114-117).  The reference copies the node's problem into the scratch
     // `a` and solves the copy; the node is discarded after this step either way, so its own clone is
-    // solved in place here -- same state, one device-to-device clone fewer per node.
-    std::vector<void *> a(W);
+    // solved in place here -- same state, one device-to-device clone fewer per node.  A node whose last
+    // solve ended OPT / UNBND, or whose re-solve was done ahead, goes through zero pivots and is not passed on.
+    std::vector<void *> a(W), need;
     std::vector<int> before(W);
     for (size_t w = 0; w < W; w++) {
       a[w] = leafContainer[w]->prob;
       before[w] = api->get_it_cnt(a[w]);
+      if (leafContainer[w]->repiv >= 0) continue;
+      const int st = api->get_status(a[w]);
+      if (st != MVX_OPT && st != MVX_UNBND) need.push_back(a[w]);
     }
-    api->simplex_batch(a.data(), (int)W, nullptr, nullptr);
+    if (!need.empty()) {
+      finalize(pend); // the engine runs one batch at a time
+      api->simplex_batch(need.data(), (int)need.size(), nullptr, nullptr);
+    }
     tA += now() - t0; t0 = now();
     // B. replay in queue order
-    std::vector<std::vector<mvx_bnb_event>> node_events(W);
-    std::vector<Branch> branches;
+    Round cur;
+    cur.node_events.resize(W);
+    std::vector<Branch> &branches = cur.branches;
     size_t processed = 0;
     for (size_t w = 0; w < W; w++) {
       if (prm.max_nodes > 0 && count >= prm.max_nodes) {
@@ -627,8 +686,8 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       }
       std::shared_ptr<MVOLP::NodeData> node = leafContainer[w];
       void *aw = a[w];
-      rec.sink = &node_events[w];
-      rec.pivots += api->get_it_cnt(aw) - before[w];
+      rec.sink = &cur.node_events[w];
+      rec.pivots += (node->repiv >= 0) ? node->repiv : api->get_it_cnt(aw) - before[w];
       processed++;
       rec.emit(MVX_EV_PREGNANT, node->oid, api->get_obj_val(aw), 0.0, 0, 0);
       double ti = now();
@@ -711,6 +770,8 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
         br.before2 = api->get_it_cnt(br.S2->prob);
         br.before3 = api->get_it_cnt(br.S3->prob);
         branches.push_back(br);
+        leafContainer.push_back(br.S2); // the queue order bs.cpp:297-298 gives them
+        leafContainer.push_back(br.S3);
         if (count > prm.loop_limit) { // bs.cpp:320-323
           hit_limit = 1;
           count++;
@@ -720,33 +781,51 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       }
       count++;
     }
-    tB += now() - t0; t0 = now();
-    // C. every child of this round is an independent LP (bs.cpp:279,287): one batched solve
-    std::vector<void *> kids;
-    for (auto &br : branches) {
-      kids.push_back(br.S2->prob);
-      kids.push_back(br.S3->prob);
-    }
-    if (!kids.empty()) api->simplex_batch(kids.data(), (int)kids.size(), nullptr, nullptr);
-    tC += now() - t0; t0 = now();
-    for (auto &br : branches) {
-      rec.pivots += (api->get_it_cnt(br.S2->prob) - br.before2) + (api->get_it_cnt(br.S3->prob) - br.before3);
-      br.S2->upperBound = api->get_obj_val(br.S2->prob);
-      br.S3->upperBound = api->get_obj_val(br.S3->prob);
-      rec.bound[(size_t)br.S2->oid] = br.S2->upperBound;
-      rec.bound[(size_t)br.S3->oid] = br.S3->upperBound;
-      leafContainer.push_back(br.S2);
-      leafContainer.push_back(br.S3);
-      rec.sink = &node_events[br.slot];
-      rec.emit(MVX_EV_CANDIDATE, br.S2->oid, br.S2->upperBound, 0.0, 0, 0);
-      rec.emit(MVX_EV_CANDIDATE, br.S3->oid, br.S3->upperBound, 0.0, 0, 0);
-    }
     rec.sink = nullptr;
-    for (size_t w = 0; w < W; w++) rec.events.insert(rec.events.end(), node_events[w].begin(), node_events[w].end());
+    tB += now() - t0;
+    // C. every child of this round is an independent LP (bs.cpp:279,287): one batched solve, on the worker
+    // thread; then, for the children found infeasible, the re-solve bs.cpp:117 will ask for when they are
+    // popped (it depends on nothing that happens in between), so that popping never has to solve.
+    finalize(pend); // one round in flight at a time; its events come before this round's
+    for (auto &br : branches) {
+      cur.kids.push_back(br.S2->prob);
+      cur.kids.push_back(br.S3->prob);
+    }
+    cur.active = true;
+    pend = std::move(cur);
+    if (!pend.kids.empty()) {
+      Round *R = &pend;
+      for (void *k : R->kids) inflight.insert(k);
+      const size_t nk = R->kids.size();
+      R->after1.assign(nk, 0);
+      R->repiv.assign(nk, -1);
+      R->obj1.assign(nk, 0.0);
+      auto work = [api, R, nk]() {
+        api->simplex_batch(R->kids.data(), (int)nk, nullptr, nullptr);
+        std::vector<void *> again;
+        std::vector<size_t> idx;
+        for (size_t k = 0; k < nk; k++) {
+          R->after1[k] = api->get_it_cnt(R->kids[k]);
+          R->obj1[k] = api->get_obj_val(R->kids[k]);
+          if (api->get_status(R->kids[k]) == MVX_NOFEAS) {
+            again.push_back(R->kids[k]);
+            idx.push_back(k);
+          }
+        }
+        if (!again.empty()) {
+          api->simplex_batch(again.data(), (int)again.size(), nullptr, nullptr);
+          for (size_t t = 0; t < idx.size(); t++) R->repiv[idx[t]] = api->get_it_cnt(again[t]) - R->after1[idx[t]];
+        }
+      };
+      if (prm.window > 1 && !std::getenv("MVX_BNB_SYNC")) pend.fut = std::async(std::launch::async, work);
+      else work();
+    }
     leafContainer.erase(leafContainer.begin(), leafContainer.begin() + (long)processed);
-    tD += now() - t0;
   }
-  if (timing) std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f)  C %.1f ms  D %.1f ms\n", tA * 1e3, tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tC * 1e3, tD * 1e3);
+  finalize(pend);
+  if (timing)
+    std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f)  waiting for child solves %.1f ms\n", tA * 1e3,
+                 tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tWait * 1e3);
   leafContainer.clear();
   pack_result(res, rec, id, count, has_incumbent, bestLower, incumbent_oid, n0, xbest, hit_limit);
   return 0;

@@ -777,6 +777,7 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
   SolveJob J;
   if (!job_prepare(J, P, parm)) return J.rc;
   Context &c = ctx();
+  HIPCHECK(hipSetDevice(c.dev)); // the current device is per host thread (the B&B driver solves from a worker thread)
   J.sc = &c.main;
   job_begin(c, J);
   for (;;) {
@@ -894,6 +895,7 @@ static int batch_finish_slot(BatchCtx &bc, int k, mvx_prob *P) {
 int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, int *rcs) {
   if (count <= 0) return 0;
   Context &c = ctx();
+  HIPCHECK(hipSetDevice(c.dev)); // per host thread, see engine_simplex
   mvx_smcp parm;
   if (parm_in) parm = *parm_in;
   else mvx_init_smcp(&parm);
