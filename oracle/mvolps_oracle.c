@@ -6,6 +6,10 @@
  * results are pinned against scipy/HiGHS fixtures (tests/golden).  "parity unpinned"
  * with respect to GLPK's own pivot sequence.
  *
+ * Pivot rules (each one mirrored by mvolps_amd/csrc/kernels.hip): primal and dual devex pricing, bounded
+ * ratio tests with bound flips, a phase 1 that carries its infeasibility-sum row through the pivots, bound
+ * perturbation and Bland's rule against stalling.
+ *
  * Determinism contract (mirrored by the HIP engine, bit for bit):
  *   - every product-sum that feeds the tableau uses fma() exactly where written here,
  *     and nowhere else (build with -ffp-contract=off);

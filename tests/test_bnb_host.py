@@ -184,3 +184,22 @@ def test_minimisation_problem_in_repaired_mode(orc, node_strat, window):
     refq = oracle.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=1, node_strat=node_strat, max_nodes=300)
     gotq = bnb.branch_and_bound(lpgen.load_setcover(orc, A, c), quirks=1, node_strat=node_strat, max_nodes=300, table=tab, window=window)
     same_result(gotq, refq)
+
+
+def test_overlapped_and_inline_child_solves_agree(orc, monkeypatch):
+    """The window driver solves each round's children on a worker thread while it replays the next window;
+    MVX_BNB_SYNC=1 keeps everything on the calling thread.  Same result either way, and the same as the
+    oracle's node-at-a-time restatement (infeasible children included: their pop-time re-solve is done ahead)."""
+    from oracle import oracle
+
+    A, b, c, U = synth.dense_ilp(10, 20, 4, 3)
+    tab = oracle_table(orc)
+    ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=0, max_nodes=4000)
+    got = {}
+    for mode in ("async", "sync"):
+        if mode == "sync":
+            monkeypatch.setenv("MVX_BNB_SYNC", "1")
+        got[mode] = bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=0, max_nodes=4000, table=tab, window=8)
+        same_result(got[mode], ref)
+    assert any(p == 1 for p in ref["prune"]), "the case must contain infeasible nodes"
+    assert ref["count"] > 50
