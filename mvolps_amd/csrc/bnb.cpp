@@ -121,7 +121,8 @@ CutContainer generateCut3(const mvx_lp_api *api, const void *in, int j) {
   std::vector<double> rv((size_t)n + 1);
   std::vector<int> ri((size_t)n + 1);
   for (int i = 1; i <= m; i++) {
-    if (work[i] == 0.0) continue; // adds work[i]*val == +-0 to finite sums: no effect on any bit
+    // no shortcut for work[i] == 0: an earlier cut of this formula may have left inf / NaN coefficients in the
+    // model (gmi.cpp:73 with absent bounds), and 0 * inf is NaN -- bs.cpp goes through every row, so does this
     const int len2 = api->get_mat_row(in, i, ri.data(), rv.data());
     const double wi = work[i];
     for (int k = 1; k <= len2; k++) work[m + k] += wi * rv[k];

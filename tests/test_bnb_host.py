@@ -203,3 +203,16 @@ def test_overlapped_and_inline_child_solves_agree(orc, monkeypatch):
         same_result(got[mode], ref)
     assert any(p == 1 for p in ref["prune"]), "the case must contain infeasible nodes"
     assert ref["count"] > 50
+
+
+def test_reference_cut_formula_with_non_finite_rows(orc):
+    """Bug-compatible cuts (gmi.cpp:73 with absent bounds) can leave inf / NaN coefficients in the model; a later
+    back-substitution (gmi.cpp:81-89) multiplies them by zero weights, which is NaN, not zero.  The driver must
+    go through every row like bs.cpp does (found by scripts/fuzz.py, seed 777)."""
+    from oracle import oracle
+
+    A, b, c, U = synth.dense_ilp(6, 11, 7025, 2)
+    kw = dict(quirks=1, cut_strat=1, max_nodes=120)
+    ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), **kw)
+    got = bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), table=oracle_table(orc), **kw)
+    same_result(got, ref)
