@@ -942,17 +942,18 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     active++;
   }
   int depth = 8; // queue-ahead depth per sync: 8, 16, 32 (a sweep of 4..16 / 8..64 moved B&B throughput by < 3 %)
+  int Kact = K;  // occupied slots are kept in positions 0..Kact-1: a launch carries no idle slot
   while (active > 0) {
     // (two half-batches on two streams were measured: no gain -- kernels of different streams do
     // not overlap usefully here, the update is bandwidth-bound and the select is tiny)
     for (int d = 0; d < depth; d++) {
-      launch_select(bc.d_ctl, bc.stream, K);
-      launch_update(bc.d_ctl, m_max, n_max, bc.stream, K);
+      launch_select(bc.d_ctl, bc.stream, Kact);
+      launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact);
     }
-    launch_export(bc.d_ctl, bc.d_stage, m_max, n_max, 0, bc.stream, K, bc.stage_stride);
-    HIPCHECK(hipMemcpyAsync(bc.h_stage, bc.d_stage, bc.stage_stride * K, hipMemcpyDeviceToHost, bc.stream));
+    launch_export(bc.d_ctl, bc.d_stage, m_max, n_max, 0, bc.stream, Kact, bc.stage_stride);
+    HIPCHECK(hipMemcpyAsync(bc.h_stage, bc.d_stage, bc.stage_stride * Kact, hipMemcpyDeviceToHost, bc.stream));
     HIPCHECK(hipStreamSynchronize(bc.stream));
-    for (int k = 0; k < K; k++) {
+    for (int k = 0; k < Kact; k++) {
       const int i = slot[(size_t)k];
       if (i < 0) continue;
       Ctl snap;
@@ -973,11 +974,23 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
         slot[(size_t)k] = pending[next++];
         batch_fill_slot(bc, k, probs[slot[(size_t)k]], parm);
         active++;
-      } else {
-        bc.h_ctl[k].done = D_FAIL; // idle
-        bc.h_ctl[k].T = nullptr;
-        HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], &bc.h_ctl[k], sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
       }
+    }
+    // Nothing left to refill with: close the gaps.  The grid of every launch is sized for its slots, and an
+    // idle slot of a large tableau still costs thousands of workgroups that start only to leave (4096x8192:
+    // 4369 per slot, ~5 us), so the control block of the last occupied slot moves into each hole.  Its
+    // pointers keep addressing the scratch area it was given.
+    for (int k = 0; k < Kact; k++) {
+      if (slot[(size_t)k] >= 0) continue;
+      int j = Kact - 1;
+      while (j > k && slot[(size_t)j] < 0) j--;
+      if (j > k) {
+        HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], &bc.d_ctl[j], sizeof(Ctl), hipMemcpyDeviceToDevice, bc.stream));
+        bc.h_ctl[k] = bc.h_ctl[j];
+        slot[(size_t)k] = slot[(size_t)j];
+        slot[(size_t)j] = -1;
+      }
+      Kact = j > k ? j : k;
     }
     depth = std::min(depth * 2, 32);
   }
