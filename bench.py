@@ -202,7 +202,9 @@ def main():
         raise SystemExit("cannot bind device %d" % dev_index)
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    # MVX_BENCH_FORCE_DIST=1: take the process-group path at world size 1 too (checks the RCCL barrier /
+    # all-reduce plumbing on a one-GPU box; run it under torch.distributed.run --nproc-per-node 1)
+    if world > 1 or os.environ.get("MVX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         if rehearsal:

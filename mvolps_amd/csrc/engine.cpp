@@ -569,6 +569,11 @@ static void job_begin(Context &c, SolveJob &J) {
   HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   J.profiled = c.prof && J.sc == &c.main;
+  // With a pivot limit the number of pivots wanted is known: queue them in one go (up to 256) instead of
+  // growing the batch 8, 16, 32, ... -- every batch boundary costs a host round trip and a generic
+  // (one-workgroup) selection step.  A primal fast-path solve that ends before the limit leaves no-op
+  // launches of ~2 us behind; dual warm starts keep the cautious growth (they usually end after a few pivots).
+  if (J.parm.it_lim > 8 && J.try_fused) J.batch = std::min(J.parm.it_lim, 256);
 }
 
 static void job_enqueue(Context &c, SolveJob &J) {
