@@ -76,14 +76,16 @@ typedef struct {
                            minimisation problem is bounded and pruned as one (best_lower is then the
                            best upper bound) */
   int lazy_pool;        /* 1 (default): generate only the cut cut.cpp:20 will actually add (the last
-                           eligible column's); 0: generate and pool every cut like bs.cpp:250-255 */
+                           eligible column's; with reference_quirks = 0 and cut_select = 0 the last column
+                           that yields a cut); 0: generate every cut like bs.cpp:250-255 */
   int cut_select;       /* reference_quirks = 0 only (changes results, hence not the
                            default path).  0: add the last generated cut (cut.cpp:20); 1: add the
                            ceil(cut_chance * k) most effective of the node's k cuts (-cf honoured) */
-  int window;           /* FIFO order without cuts, engine with a batch entry: solve the front `window`
-                           nodes of the deque together and replay bs.cpp's decisions in queue order --
-                           same tree, oids, events and incumbent as node-at-a-time;
-                           default 64, 1 = node at a time */
+  int window;           /* FIFO order, engine with a batch entry: solve the front `window` nodes of the deque
+                           together and replay bs.cpp's decisions (cuts included: the replay is in queue
+                           order, so the persistent pool sees the nodes as bs.cpp does) -- same tree, oids,
+                           events and incumbent as node-at-a-time; default 64, 1 = node
+                           at a time */
 } mvx_bnb_params;
 
 /* B&B events at the emit points of bs.cpp (message.h EventType) */

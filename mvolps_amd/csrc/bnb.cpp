@@ -375,6 +375,75 @@ void pack_result(mvx_bnb_result *res, const Recorder &rec, int id, int count, in
   res->hit_limit = hit_limit;
 }
 
+// Cut step of a branching node (bs.cpp:249-258), shared by both drivers: bug-compatible mode feeds the
+// persistent pool and appends its last cut (cut.cpp:16-21); repaired mode appends this node's own GMI cuts,
+// chosen by cut_select / -cf.
+static void add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &prm, bool quirks, CutPool &pool) {
+  if (prm.cut_strat == 0) return;
+  if (quirks) {
+    const int na = api->get_num_cols(a);
+    if (prm.lazy_pool) {
+      // only the pool's LAST cut is ever added (cut.cpp:20): generate just that one
+      for (int j = na; j >= 1; j--) {
+        if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) {
+          pool.replaceLast(generateCut3(api, a, j));
+          break;
+        }
+      }
+    } else {
+      for (int j = 1; j <= na; j++) {
+        CutContainer result = generateCut3(api, a, j);
+        if (result.oid != -1) pool.addToPool(std::move(result));
+      }
+    }
+    pool.addCutConstraint(a);
+    return;
+  }
+  const int na = api->get_num_cols(a);
+  std::vector<CutContainer> local;
+  std::vector<double> eff;
+  if (prm.cut_select == 0 && prm.lazy_pool) {
+    // only the last cut generated would be appended (cut.cpp:20): find it from the far end instead of
+    // generating one cut per basic integer column (each is a tableau row read + an O(m n) back-substitution)
+    for (int j = na; j >= 1 && local.empty(); j--) {
+      double e = 0.0;
+      CutContainer c = generateCutGMI(api, a, j, &e);
+      if (c.oid != -1) {
+        local.push_back(std::move(c));
+        eff.push_back(e);
+      }
+    }
+  } else {
+    for (int j = 1; j <= na; j++) {
+      double e = 0.0;
+      CutContainer c = generateCutGMI(api, a, j, &e);
+      if (c.oid != -1) {
+        local.push_back(std::move(c));
+        eff.push_back(e);
+      }
+    }
+  }
+  if (local.empty()) return;
+  int take = 1;
+  if (prm.cut_select == 1) {
+    take = (int)std::ceil(prm.cut_chance * (double)local.size());
+    take = std::max(1, std::min(take, (int)local.size()));
+  }
+  std::vector<char> used(local.size(), 0);
+  for (int t = 0; t < take; t++) {
+    int best = -1;
+    if (prm.cut_select == 0) best = (int)local.size() - 1; // cut.cpp:20: the last one
+    else
+      for (int q = 0; q < (int)local.size(); q++)
+        if (!used[(size_t)q] && (best < 0 || eff[(size_t)q] > eff[(size_t)best])) best = q; // ties: first generated
+    used[(size_t)best] = 1;
+    const CutContainer &cc = local[(size_t)best];
+    const int index = api->add_rows(a, 1);
+    api->set_mat_row(a, index, (int)cc.inds.size() - 1, cc.inds.data(), cc.vals.data());
+    api->set_row_bnds(a, index, MVX_LO, cc.lb, 0);
+  }
+}
+
 int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm, mvx_bnb_result *res) { // bs.cpp:54
   MVOLP::ParameterObj params(api, prob, prm);
   CutPool pool(api);
@@ -458,57 +527,7 @@ int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm,
         if (i != 0) acc += getFract(api->get_col_prim(a, i)); // bs.cpp:229-233
       leafContainer.erase(leafContainer.begin() + index);       // bs.cpp:247
 
-      if (params.IsCutEnabled() && quirks) { // bs.cpp:249-258
-        const int na = api->get_num_cols(a);
-        if (prm.lazy_pool) {
-          // only the pool's LAST cut is ever added (cut.cpp:20): generate just that one
-          for (int j = na; j >= 1; j--) {
-            if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) {
-              pool.replaceLast(generateCut3(api, a, j));
-              break;
-            }
-          }
-        } else {
-          for (int j = 1; j <= na; j++) {
-            CutContainer result = generateCut3(api, a, j);
-            if (result.oid != -1) pool.addToPool(std::move(result));
-          }
-        }
-        pool.addCutConstraint(a);
-      } else if (params.IsCutEnabled()) {
-        // repaired cuts (reference_quirks = 0): this node's own cuts, chosen by cut_select / -cf
-        const int na = api->get_num_cols(a);
-        std::vector<CutContainer> local;
-        std::vector<double> eff;
-        for (int j = 1; j <= na; j++) {
-          double e = 0.0;
-          CutContainer c = generateCutGMI(api, a, j, &e);
-          if (c.oid != -1) {
-            local.push_back(std::move(c));
-            eff.push_back(e);
-          }
-        }
-        if (!local.empty()) {
-          int take = 1;
-          if (prm.cut_select == 1) {
-            take = (int)std::ceil(prm.cut_chance * (double)local.size());
-            take = std::max(1, std::min(take, (int)local.size()));
-          }
-          std::vector<char> used(local.size(), 0);
-          for (int t = 0; t < take; t++) {
-            int best = -1;
-            if (prm.cut_select == 0) best = (int)local.size() - 1; // cut.cpp:20: the last one
-            else
-              for (int q = 0; q < (int)local.size(); q++)
-                if (!used[(size_t)q] && (best < 0 || eff[(size_t)q] > eff[(size_t)best])) best = q; // ties: first generated
-            used[(size_t)best] = 1;
-            const CutContainer &cc = local[(size_t)best];
-            const int index = api->add_rows(a, 1);
-            api->set_mat_row(a, index, (int)cc.inds.size() - 1, cc.inds.data(), cc.vals.data());
-            api->set_row_bnds(a, index, MVX_LO, cc.lb, 0);
-          }
-        }
-      }
+      add_node_cuts(api, a, prm, quirks, pool); // bs.cpp:249-258
       const int pick = params.pickVar(vars);         // bs.cpp:260
       const double bound = api->get_col_prim(a, pick); // bs.cpp:261
       rec.emit(MVX_EV_BRANCHED, node->oid, node->upperBound, acc, (int)vars.size(), pick);
@@ -613,6 +632,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
   };
   Round pend;
   std::unordered_set<const void *> inflight;
+  CutPool pool(api); // persistent across nodes in bug-compatible mode (cut.h:15-23)
   const bool timing = std::getenv("MVX_BNB_TIMING") != nullptr;
   double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tWait = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -737,6 +757,9 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
         double acc = 0;
         for (int i : vars)
           if (i != 0) acc += getFract(api->get_col_prim(aw, i));
+        // cuts go onto the node's own problem (the serial driver's scratch copy `a`): both children inherit them.
+        // The replay runs in queue order, so the persistent pool sees the nodes in bs.cpp's order.
+        add_node_cuts(api, aw, prm, quirks, pool);
         const int pick = params.pickVar(vars);
         rec.emit(MVX_EV_BRANCHED, node->oid, node->upperBound, acc, (int)vars.size(), pick);
         Branch br;
@@ -892,7 +915,7 @@ int mvx_branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params *
     params = &dflt;
   }
   if (!api) api = &g_hip_api;
-  if (api->simplex_batch && params->node_strat == 0 && params->cut_strat == 0 && params->window > 1)
+  if (api->simplex_batch && params->node_strat == 0 && params->window > 1)
     return branchAndBoundWindow(api, prob, *params, res);
   return branchAndBound(api, prob, *params, res);
 }

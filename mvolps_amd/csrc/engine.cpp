@@ -73,7 +73,12 @@ struct SolveCtx {
 
 struct Context {
   int dev = -1;
+  bool aux_ready = false;
   SolveCtx main;
+  // single-handle solves issued from inside a batch call (a lone pending handle, the phase-1 fallback) run on a
+  // context of their own: the batch call may come from the B&B driver's worker thread while the calling thread
+  // uses `main` for cut rows and solution queries
+  SolveCtx aux;
   // slab recycling (B&B clones come and go at one size)
   std::multimap<size_t, void *> free_slabs;
   size_t cached_bytes = 0;
@@ -778,12 +783,16 @@ static bool job_prepare(SolveJob &J, mvx_prob *P, const mvx_smcp *parm) {
   return true;
 }
 
-int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
+static int engine_simplex_on(mvx_prob *P, const mvx_smcp *parm, bool aux) {
   SolveJob J;
   if (!job_prepare(J, P, parm)) return J.rc;
   Context &c = ctx();
   HIPCHECK(hipSetDevice(c.dev)); // the current device is per host thread (the B&B driver solves from a worker thread)
-  J.sc = &c.main;
+  if (aux && !c.aux_ready) {
+    init_solve_ctx(c.aux);
+    c.aux_ready = true;
+  }
+  J.sc = aux ? &c.aux : &c.main;
   job_begin(c, J);
   for (;;) {
     job_enqueue(c, J);
@@ -792,6 +801,8 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) {
   }
   return J.rc;
 }
+
+int engine_simplex(mvx_prob *P, const mvx_smcp *parm) { return engine_simplex_on(P, parm, false); }
 
 // ------------------------------------------------------------------------ batched solves
 // Independent node LPs (the two children of a branch, a window of open B&B nodes) advance together:
@@ -928,7 +939,8 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   }
   if (pending.size() == 1) { // nothing to share a launch with
     const int i = pending[0];
-    const int rc = engine_simplex(probs[i], &parm);
+    HIPCHECK(hipStreamSynchronize(c.main.stream)); // edits queued on the main stream first
+    const int rc = engine_simplex_on(probs[i], &parm, true);
     if (rcs) rcs[i] = rc;
     return 0;
   }
@@ -1002,7 +1014,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   for (int i : fallback) {
     // the batch left this handle untouched apart from zero or more completed pivots
     probs[i]->sol_fresh = false;
-    const int rc = engine_simplex(probs[i], &parm);
+    const int rc = engine_simplex_on(probs[i], &parm, true);
     if (rcs) rcs[i] = rc;
   }
   return 0;

@@ -15,9 +15,9 @@ for k in range(int(sys.argv[2])):
     A, b, c, UU = synth.dense_ilp(m, n, seed, U)
     for kw in (dict(quirks=1, max_nodes=300), dict(quirks=0, max_nodes=800), dict(quirks=1, cut_strat=1, max_nodes=100),
                dict(quirks=0, cut_strat=1, cut_select=1, cut_chance=0.5, node_strat=1, max_nodes=400), dict(quirks=0, node_strat=1, var_strat=2, max_nodes=400),
-               dict(quirks=1, cut_strat=1, var_strat=1, node_strat=1, max_nodes=100)):
+               dict(quirks=1, cut_strat=1, var_strat=1, node_strat=1, max_nodes=100), dict(quirks=0, cut_strat=1, max_nodes=300)):
         ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, UU), **kw)
-        for window in ((1, 16) if kw.get("cut_strat", 0) == 0 and kw.get("node_strat", 0) == 0 else (1,)):
+        for window in ((1, 16, 64) if kw.get("node_strat", 0) == 0 else (1,)):
             got = bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, UU), table=tab, window=window, **kw)
             if any(repr(got[x]) != repr(ref[x]) for x in keys):
                 bad.append((m, n, seed, U, kw, window, [x for x in keys if repr(got[x]) != repr(ref[x])]))
