@@ -42,7 +42,7 @@ struct Cand {
 
 
 // Device-resident control block.  Kernels take only a pointer to it, so one launch
-// sequence (and one captured hipGraph) serves every problem handle.
+// sequence serves every problem handle and pivots can be queued ahead of the host.
 struct Ctl {
   // geometry + pointers (written by the host before a solve)
   double *T;
