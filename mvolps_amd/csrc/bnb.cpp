@@ -679,7 +679,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     // A. solve the window (bs.cpp:114-117).  The reference copies the node's problem into the scratch
     // `a` and solves the copy; the node is discarded after this step either way, so its own clone is
     // solved in place here -- same state, one device-to-device clone fewer per node.  A node whose last
-    // solve ended OPT / UNBND, or whose re-solve was done ahead, goes through zero pivots and is not passed on.
+    // solve ended OPT, or whose re-solve was done ahead, goes through zero pivots and is not passed on.
     std::vector<void *> a(W), need;
     std::vector<int> before(W);
     for (size_t w = 0; w < W; w++) {
@@ -687,7 +687,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       before[w] = api->get_it_cnt(a[w]);
       if (leafContainer[w]->repiv >= 0) continue;
       const int st = api->get_status(a[w]);
-      if (st != MVX_OPT && st != MVX_UNBND) need.push_back(a[w]);
+      if (st != MVX_OPT) need.push_back(a[w]);
     }
     if (!need.empty()) {
       finalize(pend); // the engine runs one batch at a time
@@ -808,7 +808,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     rec.sink = nullptr;
     tB += now() - t0;
     // C. every child of this round is an independent LP (bs.cpp:279,287): one batched solve, on the worker
-    // thread; then, for the children found infeasible, the re-solve bs.cpp:117 will ask for when they are
+    // thread; then, for the children found infeasible (or unbounded), the re-solve bs.cpp:117 will ask for when they are
     // popped (it depends on nothing that happens in between), so that popping never has to solve.
     finalize(pend); // one round in flight at a time; its events come before this round's
     for (auto &br : branches) {
@@ -831,7 +831,8 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
         for (size_t k = 0; k < nk; k++) {
           R->after1[k] = api->get_it_cnt(R->kids[k]);
           R->obj1[k] = api->get_obj_val(R->kids[k]);
-          if (api->get_status(R->kids[k]) == MVX_NOFEAS) {
+          const int st1 = api->get_status(R->kids[k]);
+          if (st1 == MVX_NOFEAS || st1 == MVX_UNBND) { // a re-solve of these may pivot on (fresh devex weights)
             again.push_back(R->kids[k]);
             idx.push_back(k);
           }

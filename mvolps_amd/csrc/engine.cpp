@@ -748,14 +748,14 @@ static bool job_collect(Context &c, SolveJob &J) {
   return false;
 }
 
-// A handle whose last solve ended OPT / UNBND and that has not been edited since (every edit resets
-// `status`) would go through zero pivots and come out unchanged: bs.cpp:116-117 re-solves exactly such
-// clones at every pop.  Answer from the state at hand instead of queueing launches.  NOFEAS is not in
-// the list: the dual simplex restarts its devex weights on entry, so the re-solve may pick another
-// infeasible row than the one that proved infeasibility and pivot on before it ends NOFEAS again.
+// A handle whose last solve ended OPT and that has not been edited since (every edit resets `status`)
+// would go through zero pivots and come out unchanged: bs.cpp:116-117 re-solves exactly such clones at
+// every pop.  Answer from the state at hand instead of queueing launches.  NOFEAS / UNBND are not in the
+// list: a new call restarts the devex weights, so the re-solve may pick another infeasible row (another
+// entering column) than the one that proved infeasibility (unboundedness) and pivot on before it ends there again.
 static bool already_solved(const mvx_prob *P, const mvx_smcp &parm) {
   if (!P->valid || parm.it_lim == 0) return false;
-  if (P->status != MVX_OPT && P->status != MVX_UNBND) return false;
+  if (P->status != MVX_OPT) return false;
   return P->last_tol[0] == parm.tol_bnd && P->last_tol[1] == parm.tol_dj && P->last_tol[2] == parm.tol_piv;
 }
 static void remember_tolerances(mvx_prob *P, const mvx_smcp &parm) {

@@ -433,3 +433,32 @@ def test_bland_fallback_bit_exact(gpu, orc, limit):
         gpu.set_stall_limit(0)
         orc.set_stall_limit(0)
 
+
+
+def test_resolve_without_edits_bit_exact(gpu, orc):
+    """bs.cpp:116-117 solves every node again when it is popped.  A second call on an unedited handle is a no-op
+    only after OPT; after NOFEAS / UNBND the fresh devex weights may pick another row / column and pivot on.
+    Whatever it does, the device does the same as the oracle."""
+    rng = np.random.default_rng(11)
+    seen = {}
+    for trial in range(150):
+        A, row_b, col_b, c, direction = lpgen.random_general_lp(rng, mmax=14, nmax=16)
+        if trial % 3 == 0:  # make it infeasible: two contradictory copies of row 0
+            A[1] = A[0]
+            if not A[0].any():
+                A[0, 0] = A[1, 0] = 1.0
+            row_b[0] = (UP, 0.0, 1.0)
+            row_b[1] = (LO, 3.0, 0.0)
+            col_b = [(DB, -5.0, 5.0)] * A.shape[1]
+        g, o = gpu.create(), orc.create()
+        for P in (g, o):
+            P.load_general(A, row_b, col_b, c, direction=direction)
+            P.simplex()
+        first = (o.status, o.it_cnt)
+        for P in (g, o):
+            P.rc2 = P.simplex()
+        assert g.rc2 == o.rc2
+        assert_same_state(g, o, "second solve, trial %d" % trial)
+        seen.setdefault(first[0], []).append(o.it_cnt - first[1])
+    assert capi.OPT in seen and capi.NOFEAS in seen and capi.UNBND in seen
+    assert all(d == 0 for d in seen[capi.OPT])
