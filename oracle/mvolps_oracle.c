@@ -956,7 +956,7 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
       P->status = ORC_FEAS;
       return ORC_EITLIM;
     }
-    int q = (parm->meth == 2) ? 1 : price(P, &TT(P, 0, 0), sgn, ctl.tol_dj, &sdir, 0, NULL); /* existence only */
+    int q = price(P, &TT(P, 0, 0), sgn, ctl.tol_dj, &sdir, 0, NULL); /* existence only */
     r = (q == 0) ? dual_simplex(P, &ctl) : primal_phase1(P, &ctl);
     if (r == R_PFEAS) continue;
     if (r == R_NOFEAS) { P->status = ORC_NOFEAS; return 0; }

@@ -63,7 +63,7 @@ typedef struct orc_prob orc_prob;
 
 typedef struct {
   int msg_lev;
-  int meth;       /* 1 = auto (primal / dual / phase-1 chosen from the basis), 2 = primal only */
+  int meth;       /* 1 = automatic (primal / dual / phase 1 chosen from the basis); nothing else is implemented */
   int it_lim;     /* pivot limit for THIS call; <0 = none */
   double tol_bnd; /* primal feasibility tolerance (relative: tol*(1+|bound|)) */
   double tol_dj;  /* dual feasibility tolerance (absolute) */
