@@ -36,6 +36,26 @@ for k in range(n_gen):
         P.simplex()
     if not same(g, o):
         bad.append(("general-warm", k))
+    # more warm starts on the same handles: a row bound, the objective, the direction, a second solve as is
+    i = int(rng.integers(1, A.shape[0] + 1))
+    t2, v2 = int(rng.choice([capi.UP, capi.LO, capi.DB, capi.FR])), float(rng.integers(-6, 7))
+    for P in (g, o):
+        P.api.set_row_bnds(P.h, i, t2, v2, v2 + 2.0)
+        P.simplex()
+    if not same(g, o):
+        bad.append(("row-warm", k))
+    jc = int(rng.integers(1, A.shape[1] + 1)); vc = float(rng.integers(-5, 6))
+    for P in (g, o):
+        P.api.set_obj_coef(P.h, jc, vc)
+        P.simplex()
+    if not same(g, o):
+        bad.append(("obj-warm", k))
+    for P in (g, o):
+        P.api.set_obj_dir(P.h, capi.MIN if direction == capi.MAX else capi.MAX)
+        P.simplex()
+        P.simplex()
+    if not same(g, o):
+        bad.append(("dir-warm", k))
 print("general done", time.time() - t0, "bad", len(bad), flush=True)
 for k in range(120):
     m, n = int(rng.integers(20, 400)), int(rng.integers(20, 700))
