@@ -38,6 +38,7 @@ void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1);
 void launch_p1_head(Ctl *, hipStream_t);
 void launch_p1_select(Ctl *, hipStream_t);
 void launch_p1_fix(Ctl *, int n, hipStream_t);
+void launch_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count, hipStream_t);
 void launch_rowcomb(Ctl *, int m, int n, int respect_done, hipStream_t);
 void launch_shift_nonbasic(double *T, int ld, int m, int jj, double delta, hipStream_t);
 void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub, hipStream_t);
@@ -816,6 +817,8 @@ struct BatchCtx {
   int m_cap = 0, ld = 0; // per-slot scratch capacity
   hipStream_t stream = nullptr;
   Ctl *d_ctl = nullptr, *h_ctl = nullptr;
+  Ctl *d_fill = nullptr, *h_fill = nullptr; // packed control blocks of the slots filled at one sync point
+  int *d_fidx = nullptr, *h_fidx = nullptr; // ... and their slot numbers
   unsigned char *scratch = nullptr;
   size_t scratch_stride = 0;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
@@ -833,6 +836,10 @@ static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
   HIPCHECK(hipStreamSynchronize(bc.stream));
   if (bc.d_ctl) HIPCHECK(hipFree(bc.d_ctl));
   if (bc.h_ctl) HIPCHECK(hipHostFree(bc.h_ctl));
+  if (bc.d_fill) HIPCHECK(hipFree(bc.d_fill));
+  if (bc.h_fill) HIPCHECK(hipHostFree(bc.h_fill));
+  if (bc.d_fidx) HIPCHECK(hipFree(bc.d_fidx));
+  if (bc.h_fidx) HIPCHECK(hipHostFree(bc.h_fidx));
   if (bc.scratch) HIPCHECK(hipFree(bc.scratch));
   if (bc.d_stage) HIPCHECK(hipFree(bc.d_stage));
   if (bc.h_stage) HIPCHECK(hipHostFree(bc.h_stage));
@@ -841,6 +848,10 @@ static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
   bc.ld = std::max(ld, bc.ld);
   HIPCHECK(hipMalloc((void **)&bc.d_ctl, sizeof(Ctl) * bc.slots));
   HIPCHECK(hipHostMalloc((void **)&bc.h_ctl, sizeof(Ctl) * bc.slots));
+  HIPCHECK(hipMalloc((void **)&bc.d_fill, sizeof(Ctl) * bc.slots));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_fill, sizeof(Ctl) * bc.slots));
+  HIPCHECK(hipMalloc((void **)&bc.d_fidx, sizeof(int) * bc.slots));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_fidx, sizeof(int) * bc.slots));
   bc.scratch_stride = align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256) +
                       2 * align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) + align_up((size_t)(bc.m_cap + 1) * 8, 256) +
                       align_up((size_t)bc.ld * 8, 256);
@@ -874,7 +885,24 @@ static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &pa
   h->phase = PH_START; h->done = D_RUN; h->budget = pivot_budget(P, parm);
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->fstate = F_OFF;
-  HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], h, sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
+}
+
+// upload the control blocks of the slots filled since the last flush (host side: bc.h_ctl[k])
+static void batch_flush_fills(BatchCtx &bc, std::vector<int> &fills) {
+  const int cnt = (int)fills.size();
+  if (cnt == 1) {
+    const int k = fills[0];
+    HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], &bc.h_ctl[k], sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
+  } else if (cnt > 1) {
+    for (int t = 0; t < cnt; t++) {
+      bc.h_fill[t] = bc.h_ctl[fills[(size_t)t]];
+      bc.h_fidx[t] = fills[(size_t)t];
+    }
+    HIPCHECK(hipMemcpyAsync(bc.d_fill, bc.h_fill, sizeof(Ctl) * (size_t)cnt, hipMemcpyHostToDevice, bc.stream));
+    HIPCHECK(hipMemcpyAsync(bc.d_fidx, bc.h_fidx, sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice, bc.stream));
+    launch_scatter_ctl(bc.d_ctl, bc.d_fill, bc.d_fidx, cnt, bc.stream);
+  }
+  fills.clear();
 }
 
 // mirrors + status of a finished slot; layout inside the slot follows the handle's own m_cap / ld
@@ -953,11 +981,14 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   std::vector<int> slot((size_t)bc.slots, -1);
   size_t next = 0;
   int active = 0;
+  std::vector<int> fills;
   for (int k = 0; k < K && next < pending.size(); k++) {
     slot[(size_t)k] = pending[next++];
     batch_fill_slot(bc, k, probs[slot[(size_t)k]], parm);
+    fills.push_back(k);
     active++;
   }
+  batch_flush_fills(bc, fills);
   int depth = 8; // queue-ahead depth per sync: 8, 16, 32 (a sweep of 4..16 / 8..64 moved B&B throughput by < 3 %)
   int Kact = K;  // occupied slots are kept in positions 0..Kact-1: a launch carries no idle slot
   while (active > 0) {
@@ -990,9 +1021,11 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
       if (next < pending.size()) {
         slot[(size_t)k] = pending[next++];
         batch_fill_slot(bc, k, probs[slot[(size_t)k]], parm);
+        fills.push_back(k);
         active++;
       }
     }
+    batch_flush_fills(bc, fills);
     // Nothing left to refill with: close the gaps.  The grid of every launch is sized for its slots, and an
     // idle slot of a large tableau still costs thousands of workgroups that start only to leave (4096x8192:
     // 4369 per slot, ~5 us), so the control block of the last occupied slot moves into each hole.  Its

@@ -1276,6 +1276,18 @@ void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
 }
 void launch_p1_head(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_head, dim3(1), dim3(1024), 0, s, d_ctl); }
 void launch_p1_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_select, dim3(1), dim3(1024), 0, s, d_ctl); }
+// control blocks of freshly filled batch slots: one upload of the packed blocks + this scatter instead of one
+// small host-to-device copy per slot (each of those is a blit kernel of ~5 us on the device)
+__global__ __launch_bounds__(64) void k_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count) {
+  const int t = (int)blockIdx.x;
+  if (t >= count) return;
+  const unsigned *s = reinterpret_cast<const unsigned *>(&src[t]);
+  unsigned *d = reinterpret_cast<unsigned *>(&dst[idx[t]]);
+  for (int w = TIDX; w < (int)(sizeof(Ctl) / 4); w += 64) d[w] = s[w];
+}
+void launch_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count, hipStream_t s) {
+  hipLaunchKernelGGL(k_scatter_ctl, dim3(count), dim3(64), 0, s, dst, src, idx, count);
+}
 void launch_p1_fix(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_p1_fix, dim3((n + 1 + 255) / 256), dim3(256), 0, s, d_ctl); }
 void launch_rowcomb(Ctl *d_ctl, int m, int n, int respect_done, hipStream_t s) {
   const int nchunks = (m + ROWCOMB_CHUNK - 1) / ROWCOMB_CHUNK;

@@ -80,3 +80,30 @@ def test_clone_free_cycles_reuse_slabs(gpu, orc):
             res.append((ch.status, ch.it_cnt, ch.tableau()))
             del ch
         assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
+
+
+def test_columns_added_after_a_solve(gpu, orc):
+    """glp_add_cols on a solved problem (readers only do it before the first solve): the basis is dropped and
+    the next solve starts again from the slack basis, on both sides alike."""
+    from mvolps_amd import capi, synth
+
+    A, b, c = synth.dense_lp(20, 30, 3)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+        assert P.simplex() == 0
+        j0 = P.api.add_cols(P.h, 2)
+        assert j0 == 31
+        for j, (cost, ub) in ((31, (2.5, 4.0)), (32, (0.75, 1.0))):
+            P.api.set_col_bnds(P.h, j, capi.DB, 0.0, ub)
+            P.api.set_obj_coef(P.h, j, cost)
+        ind = (np.arange(33)).astype(np.int32)
+        for i in range(1, 21):
+            val = np.concatenate(([0.0], A[i - 1], [0.5 + 0.01 * i, 0.25]))
+            P.set_mat_row(i, ind, val)
+        assert P.simplex() == 0
+    assert g.status == o.status == capi.OPT
+    assert g.it_cnt == o.it_cnt and g.obj == o.obj
+    assert np.array_equal(g.tableau(), o.tableau())
+    for x, y in zip(g.basis(), o.basis()):
+        assert np.array_equal(x, y)
