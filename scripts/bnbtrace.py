@@ -1,3 +1,4 @@
+"""Kernel-trace input: window-64 B&B on the 512x1024 ILP (run under rocprofv3 --kernel-trace, then trace_busy.py)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mvolps_amd

@@ -1,3 +1,4 @@
+"""HIP-event cost per pivot (why bench.py times its per-kernel pass separately)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, mvolps_amd

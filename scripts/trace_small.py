@@ -1,3 +1,4 @@
+"""Kernel-trace / PMC input: M N [PIVOTS] pivots of a dense LP on the fused path."""
 import sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mvolps_amd
