@@ -462,3 +462,37 @@ def test_resolve_without_edits_bit_exact(gpu, orc):
         seen.setdefault(first[0], []).append(o.it_cnt - first[1])
     assert capi.OPT in seen and capi.NOFEAS in seen and capi.UNBND in seen
     assert all(d == 0 for d in seen[capi.OPT])
+
+
+@pytest.mark.parametrize("slots", [2, 3, 5])
+def test_batch_with_few_slots_refills_and_compacts(gpu, orc, slots):
+    """More handles than slots: finished slots are refilled from the pending list at every sync, and once
+    that list is empty the occupied slots are compacted so that launches carry no idle slot.  Same bits as
+    one solve per handle, whatever the slot count."""
+    import ctypes as C
+
+    try:
+        gpu.set_batch_slots(slots)
+        A, b, c, U = synth.dense_ilp(30, 60, seed=9, U=3)
+        g = lpgen.load_ilp(gpu, A, b, c, U)
+        o = lpgen.load_ilp(orc, A, b, c, U)
+        for P in (g, o):
+            P.simplex()
+        x = o.col_prim()
+        frac = [j + 1 for j in range(len(x)) if np.trunc(x[j]) != x[j]]
+        kids_g, kids_o = [], []
+        for j in frac[:7]:
+            for (t, lo, hi) in ((UP, 0.0, float(np.floor(x[j - 1]))), (LO, float(np.ceil(x[j - 1])), 0.0)):
+                for P, kids in ((g, kids_g), (o, kids_o)):
+                    ch = P.copy()
+                    P.api.set_col_bnds(ch.h, j, t, lo, hi)
+                    kids.append(ch)
+        assert len(kids_g) >= 8
+        arr = (C.c_void_p * len(kids_g))(*[k.h for k in kids_g])
+        rcs = (C.c_int * len(kids_g))()
+        assert gpu.simplex_batch(arr, len(kids_g), None, rcs) == 0
+        for kg, ko, rc in zip(kids_g, kids_o, rcs):
+            assert rc == ko.simplex()
+            assert_same_state(kg, ko, "batched child, %d slots" % slots)
+    finally:
+        gpu.set_batch_slots(64)
