@@ -25,6 +25,26 @@ namespace mvx {
 #define TIDX ((int)threadIdx.x)
 
 // MODE 0: larger k1, then smaller idx.   MODE 1: smaller k1, then larger k2, then smaller idx.
+// a / b, correctly rounded.  The fp64 division sequence of gfx950 is almost, not exactly, IEEE: about one quotient
+// in 1e8 comes out one ulp off (-0x1.6666666666663p-1 / -0x1.ffffffffffffbp-1 gives ...666p-1, the nearest double is
+// ...667p-1), which is enough to part a long B&B run from the oracle.  The residual a - q*b of a quotient that is
+// within one ulp is exact in one fma, so the better of q and its neighbour on the side the residual points to is
+// the correctly rounded quotient, whatever the native division returned.  The oracle runs the same function
+// (there the native quotient is already the nearest and comes back unchanged).
+__device__ __forceinline__ double xdiv(double a, double b) {
+  const double q = a / b;
+  const double aq = fabs(q);
+  if (!(aq > 1e-290 && aq < 1e290)) return q; // zero, subnormal range, inf, nan
+  const double r = fma(-q, b, a);
+  if (r == 0.0) return q;
+  const bool up = (r > 0.0) == (b > 0.0); // the true quotient lies above q
+  long long bits = __double_as_longlong(q);
+  bits += ((q > 0.0) == up) ? 1 : -1;
+  const double q1 = __longlong_as_double(bits);
+  const double r1 = fma(-q1, b, a);
+  return (fabs(r1) < fabs(r)) ? q1 : q;
+}
+
 template <int MODE>
 __device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b) {
   if (a.idx == 0) return false;
@@ -124,7 +144,7 @@ __device__ Cand dev_infeas_row(const KC &k, Cand *lds, const double *w) {
       up = 1;
     }
     if (viol > 0.0) {
-      Cand x{k.bland ? -(double)k.bvar[i] : viol * viol / (w ? w[i] : 1.0), 0.0, i, up}; // Bland: lowest variable number wins
+      Cand x{k.bland ? -(double)k.bvar[i] : xdiv(viol * viol, w ? w[i] : 1.0), 0.0, i, up}; // Bland: lowest variable number wins
       if (cand_better<0>(x, best)) best = x;
     }
   }
@@ -143,7 +163,7 @@ __device__ Cand dev_price(const KC &k, const double *cost, double sgn, Cand *lds
     const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
     const bool dn = (f == MVX_NU || f == MVX_NF) && dj < -tol;
     if (!up && !dn) continue;
-    const double sc = k.bland ? -(double)k.nvar[j] : (mode == 0 ? fabs(dj) : dj * dj / (mode == 1 ? k.pw[j] : 1.0));
+    const double sc = k.bland ? -(double)k.nvar[j] : (mode == 0 ? fabs(dj) : xdiv(dj * dj, mode == 1 ? k.pw[j] : 1.0));
     Cand x{sc, 0.0, j, up ? 1 : -1};
     if (cand_better<0>(x, best)) best = x;
   }
@@ -160,21 +180,21 @@ __device__ __forceinline__ bool ratio_row(double a, int sdir, double beta, doubl
   if (aa > tp) {
     if (gi < 0) return false;
     if (gi > 0) {
-      t = (lb - beta) / aa;
+      t = xdiv(lb - beta, aa);
       up = 0;
     } else {
       if (!(ub < INFINITY)) return false;
-      t = (ub - beta) / aa;
+      t = xdiv(ub - beta, aa);
       up = 1;
     }
   } else if (aa < -tp) {
     if (gi > 0) return false;
     if (gi < 0) {
-      t = (beta - ub) / (-aa);
+      t = xdiv(beta - ub, -aa);
       up = 1;
     } else {
       if (!(lb > -INFINITY)) return false;
-      t = (beta - lb) / (-aa);
+      t = xdiv(beta - lb, -aa);
       up = 0;
     }
   } else
@@ -223,7 +243,7 @@ __device__ Cand dev_dual_ratio(const KC &k, int p, int to_upper, Cand *lds) {
     } else
       continue;
     const double mag = fabs(a);
-    r = r / mag;
+    r = xdiv(r, mag);
     Cand x{r, k.bland ? -(double)k.nvar[j] : mag, j, 0};
     if (cand_better<1>(x, best)) best = x;
   }
@@ -247,11 +267,11 @@ __device__ void dev_prepare_pivot(const KC &k, Ctl *c, int p, int q, int p_up, i
   const double bound = p_up ? k.bub[p] : k.blb[p];
   for (int j = TIDX; j <= k.n; j += (int)blockDim.x) {
     const double v = rowp[j];
-    const double sj = (j == 0) ? (v - bound) / piv : v / piv;
+    const double sj = (j == 0) ? xdiv(v - bound, piv) : xdiv(v, piv);
     k.srow[j] = sj;
     if (wmode && j >= 1) {
       if (j == q) {
-        const double cc = wq / (piv * piv);
+        const double cc = xdiv(wq, piv * piv);
         k.pw[j] = cc > 1.0 ? cc : 1.0;
       } else {
         const double cc = sj * sj * wq;
@@ -518,10 +538,10 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
       k.colq[i] = a;
       if (i == 0) continue;
       if (i == p) {
-        const double cc = wp / (apq * apq);
+        const double cc = xdiv(wp, apq * apq);
         k.dw[i] = cc > 1.0 ? cc : 1.0;
       } else {
-        const double r = a / apq;
+        const double r = xdiv(a, apq);
         const double cc = r * r * wp;
         double wi = fresh_dual ? 1.0 : k.dw[i];
         if (cc > wi) wi = cc;
@@ -728,7 +748,7 @@ __global__ __launch_bounds__(256) void k_update(Ctl *c) {
   if (q0 || q1) {
 #pragma unroll
     for (int r = 0; r < TR; r++) {
-      const double qv = ci[r] / piv;
+      const double qv = xdiv(ci[r], piv);
       if (q0) v[r].x = qv;
       if (q1) v[r].y = qv;
       __builtin_amdgcn_sched_barrier(0);
@@ -738,8 +758,8 @@ __global__ __launch_bounds__(256) void k_update(Ctl *c) {
 #pragma unroll
     for (int r = 0; r < TR; r++) {
       if (i0 + r == p) {
-        v[r].x = q0 ? 1.0 / piv : -s.x;
-        v[r].y = q1 ? 1.0 / piv : -s.y;
+        v[r].x = q0 ? xdiv(1.0, piv) : -s.x;
+        v[r].y = q1 ? xdiv(1.0, piv) : -s.y;
         if (j0 == 0) v[r].x = c->xq - s.x;
       }
     }
@@ -861,7 +881,7 @@ __device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, d
   const bool up = (f == MVX_NL || f == MVX_NF) && dj > tol;
   const bool dn = (f == MVX_NU || f == MVX_NF) && dj < -tol;
   if (!up && !dn) return false;
-  x = Cand{dj * dj / w, 0.0, j, up ? 1 : -1};
+  x = Cand{xdiv(dj * dj, w), 0.0, j, up ? 1 : -1};
   return true;
 }
 
@@ -1000,15 +1020,15 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
     const double bound = p_up ? pub : plb;
     const int lf = dev_leave_flag(plb, pub, p_up);
     if (act) {
-      const double sj = (j == 0) ? (v - bound) / piv : v / piv;
+      const double sj = (j == 0) ? xdiv(v - bound, piv) : xdiv(v, piv);
       srow[j] = sj;
-      const double dnew = (j == q) ? dq / piv : fma(-dq, sj, dold_);
+      const double dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dold_);
       T[j] = dnew;
       if (j >= 1) {
         // devex weight update from the scaled pivot row (oracle: primal_step), then the next pricing
         double wn;
         if (j == q) {
-          const double cc = wq / (piv * piv);
+          const double cc = xdiv(wq, piv * piv);
           wn = cc > 1.0 ? cc : 1.0;
         } else {
           const double cc = sj * sj * wq;
@@ -1104,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
           // (about 10 temporaries each) from being interleaved, so the kernel keeps its occupancy
 #pragma unroll
           for (int r = 0; r < TR; r++) {
-            const double qv = ci[r] / piv;
+            const double qv = xdiv(ci[r], piv);
             if (q0) v[r].x = qv;
             if (q1) v[r].y = qv;
             __builtin_amdgcn_sched_barrier(0);
@@ -1114,8 +1134,8 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 #pragma unroll
           for (int r = 0; r < TR; r++) {
             if (i0 + r == p) {
-              v[r].x = q0 ? 1.0 / piv : -s.x;
-              v[r].y = q1 ? 1.0 / piv : -s.y;
+              v[r].x = q0 ? xdiv(1.0, piv) : -s.x;
+              v[r].y = q1 ? xdiv(1.0, piv) : -s.y;
               if (has0) v[r].x = c->xq - s.x;
             }
           }
@@ -1134,14 +1154,14 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
           double2 v = *ptr;
           const double ci = colq[i];
           if (i == p) {
-            v.x = q0 ? 1.0 / piv : -s.x;
-            v.y = q1 ? 1.0 / piv : -s.y;
+            v.x = q0 ? xdiv(1.0, piv) : -s.x;
+            v.y = q1 ? xdiv(1.0, piv) : -s.y;
             if (has0) v.x = c->xq - s.x;
           } else {
             v.x = fma(-ci, s.x, v.x);
             v.y = fma(-ci, s.y, v.y);
-            if (q0) v.x = ci / piv;
-            if (q1) v.y = ci / piv;
+            if (q0) v.x = xdiv(ci, piv);
+            if (q1) v.y = xdiv(ci, piv);
           }
           *ptr = v;
           if (has0) bnew[i] = v.x;

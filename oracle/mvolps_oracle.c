@@ -52,6 +52,26 @@ struct orc_prob {
   int pert_cnt;  /* bound perturbations applied (diagnostic) */
 };
 
+/* a / b, correctly rounded -- the same function as xdiv() in mvolps_amd/csrc/kernels.hip.  On this side the
+   native quotient is already the nearest double and comes back unchanged; the device's fp64 division is one
+   ulp off about once in 1e8 quotients, and the fix-up (exact residual of q and of its neighbour, keep the
+   smaller) makes both sides return the correctly rounded quotient. */
+static inline double xdiv(double a, double b) {
+  const double q = a / b;
+  const double aq = fabs(q);
+  if (!(aq > 1e-290 && aq < 1e290)) return q; /* zero, subnormal range, inf, nan */
+  const double r = fma(-q, b, a);
+  if (r == 0.0) return q;
+  const int up = (r > 0.0) == (b > 0.0);
+  long long bits;
+  memcpy(&bits, &q, sizeof bits);
+  bits += ((q > 0.0) == up) ? 1 : -1;
+  double q1;
+  memcpy(&q1, &bits, sizeof q1);
+  const double r1 = fma(-q1, b, a);
+  return (fabs(r1) < fabs(r)) ? q1 : q;
+}
+
 static int g_term_out = 1;
 static int g_stall_limit = 0; /* > 0: overrides 64 + (m+n)/8 (tests drive the anti-stalling rules with it) */
 void orc_set_stall_limit(int limit) { g_stall_limit = limit; }
@@ -562,7 +582,7 @@ static int price(const orc_prob *P, const double *cost, double sgn, double tol, 
     int dn = (f == ORC_NU || f == ORC_NF) && dj < -tol;
     if (!up && !dn) continue;
     /* Bland: lowest variable number wins; devex: d^2 / weight; else Dantzig */
-    double sc = bland ? -(double)P->nvar[j] : (pw ? dj * dj / pw[j] : fabs(dj));
+    double sc = bland ? -(double)P->nvar[j] : (pw ? xdiv(dj * dj, pw[j]) : fabs(dj));
     if (q == 0 || sc > best) { /* strict > keeps the lowest j on ties */
       best = sc;
       q = j;
@@ -598,7 +618,7 @@ static int select_infeasible_row(const orc_prob *P, double tol_bnd, int *to_uppe
       viol = beta - ub;
       up = 1;
     }
-    double sc = bland ? -(double)P->bvar[i] : viol * viol / (w ? w[i] : 1.0);
+    double sc = bland ? -(double)P->bvar[i] : xdiv(viol * viol, w ? w[i] : 1.0);
     if (viol > 0.0 && (p == 0 || sc > best)) {
       best = sc;
       p = i;
@@ -616,8 +636,8 @@ static void pivot(orc_prob *P, int p, int q, double bound, int leave_flag, doubl
   double piv = rowp[q];
   double xq = nb_value(P->nflag[q], P->nlb[q], P->nub[q]);
   double *s = (double *)xcalloc((size_t)n + 1, sizeof(double));
-  s[0] = (rowp[0] - bound) / piv;
-  for (int j = 1; j <= n; j++) s[j] = rowp[j] / piv;
+  s[0] = xdiv(rowp[0] - bound, piv);
+  for (int j = 1; j <= n; j++) s[j] = xdiv(rowp[j], piv);
 #pragma omp parallel for schedule(static) if ((long)m * n >= 262144)
   for (int i = 0; i <= m; i++) {
     if (i == p) continue;
@@ -625,16 +645,16 @@ static void pivot(orc_prob *P, int p, int q, double bound, int leave_flag, doubl
     double ci = row[q];
     double nci = -ci;
     for (int j = 0; j <= n; j++) row[j] = fma(nci, s[j], row[j]);
-    row[q] = ci / piv;
+    row[q] = xdiv(ci, piv);
   }
   if (xrow) { /* one more row i != p (the device keeps it in tableau row m+1) */
     double ci = xrow[q];
     double nci = -ci;
     for (int j = 0; j <= n; j++) xrow[j] = fma(nci, s[j], xrow[j]);
-    xrow[q] = ci / piv;
+    xrow[q] = xdiv(ci, piv);
   }
   for (int j = 1; j <= n; j++) rowp[j] = -s[j];
-  rowp[q] = 1.0 / piv;
+  rowp[q] = xdiv(1.0, piv);
   rowp[0] = xq - s[0];
   free(s);
   /* swap basis bookkeeping */
@@ -673,18 +693,18 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
     int up;
     if (aa > ctl->tol_piv) { /* basic variable increases */
       if (g && g[i] < 0) continue;               /* above ub, moving further away */
-      if (g && g[i] > 0) { t = (P->blb[i] - beta) / aa; up = 0; } /* reaches lb from below */
+      if (g && g[i] > 0) { t = xdiv(P->blb[i] - beta, aa); up = 0; } /* reaches lb from below */
       else {
         if (!(P->bub[i] < INF)) continue;
-        t = (P->bub[i] - beta) / aa;
+        t = xdiv(P->bub[i] - beta, aa);
         up = 1;
       }
     } else if (aa < -ctl->tol_piv) { /* decreases */
       if (g && g[i] > 0) continue;
-      if (g && g[i] < 0) { t = (beta - P->bub[i]) / (-aa); up = 1; }
+      if (g && g[i] < 0) { t = xdiv(beta - P->bub[i], -aa); up = 1; }
       else {
         if (!(P->blb[i] > -INF)) continue;
-        t = (beta - P->blb[i]) / (-aa);
+        t = xdiv(beta - P->blb[i], -aa);
         up = 0;
       }
     } else
@@ -716,11 +736,11 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
     const double apq = TT(P, p, q), wq = w[q];
     for (int j = 1; j <= P->n; j++) {
       if (j == q) continue;
-      double r = TT(P, p, j) / apq;
+      double r = xdiv(TT(P, p, j), apq);
       double c = r * r * wq;
       if (c > w[j]) w[j] = c;
     }
-    double c = wq / (apq * apq);
+    double c = xdiv(wq, apq * apq);
     w[q] = c > 1.0 ? c : 1.0;
   }
   pivot(P, p, q, bound, leave_flag_for(P->blb[p], P->bub[p], p_up), ctl->xrow);
@@ -883,7 +903,7 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
       } else
         continue;
       double mag = fabs(a);
-      r = r / mag;
+      r = xdiv(r, mag);
       if (bland) mag = -(double)P->nvar[j]; /* tie-break among equal ratios */
       if (better(r, mag, j, br, bmag, q)) {
         br = r;
@@ -896,11 +916,11 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
       const double apq = TT(P, p, q), wp = w[p];
       for (int i = 1; i <= m; i++) {
         if (i == p) continue;
-        double r = TT(P, i, q) / apq;
+        double r = xdiv(TT(P, i, q), apq);
         double c = r * r * wp;
         if (c > w[i]) w[i] = c;
       }
-      double c = wp / (apq * apq);
+      double c = xdiv(wp, apq * apq);
       w[p] = c > 1.0 ? c : 1.0;
     }
     double bound = to_upper ? P->bub[p] : P->blb[p];
