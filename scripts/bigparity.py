@@ -6,7 +6,7 @@ import mvolps_amd
 from mvolps_amd import synth
 from oracle import oracle
 gpu, orc = mvolps_amd.api(), oracle.api()
-for (m, n, seed) in [(1024, 2048, 12345), (777, 3001, 5), (2048, 4096, 12345), (1500, 600, 9)]:
+for (m, n, seed) in [(1024, 2048, 12345), (777, 3001, 5), (2048, 4096, 12345), (1500, 600, 9), (4096, 8192, 12345)]:
     A, b, c = synth.dense_lp(m, n, seed)
     g, o = gpu.create(), orc.create()
     t = time.time(); g.load_dense(A, b, c); g.simplex(); tg = time.time() - t
