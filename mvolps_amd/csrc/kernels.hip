@@ -25,9 +25,10 @@ namespace mvx {
 #define TIDX ((int)threadIdx.x)
 
 // MODE 0: larger k1, then smaller idx.   MODE 1: smaller k1, then larger k2, then smaller idx.
-// a / b, correctly rounded.  The fp64 division sequence of gfx950 is almost, not exactly, IEEE: about one quotient
-// in 1e8 comes out one ulp off (-0x1.6666666666663p-1 / -0x1.ffffffffffffbp-1 gives ...666p-1, the nearest double is
-// ...667p-1), which is enough to part a long B&B run from the oracle.  The residual a - q*b of a quotient that is
+// a / b, correctly rounded.  The fp64 division sequence of gfx950 is almost, not exactly, IEEE: a quotient that lies
+// very close to the midpoint of two doubles can come out one ulp off (-0x1.6666666666663p-1 / -0x1.ffffffffffffbp-1
+// gives ...666p-1, the nearest double is ...667p-1).  Random operands never hit it (scripts/divcheck.py: 0 of 3e8), the
+// near-rational entries of a tableau do: one such quotient parted a 641-node B&B run from the oracle.  The residual a - q*b of a quotient that is
 // within one ulp is exact in one fma, so the better of q and its neighbour on the side the residual points to is
 // the correctly rounded quotient, whatever the native division returned.  The oracle runs the same function
 // (there the native quotient is already the nearest and comes back unchanged).

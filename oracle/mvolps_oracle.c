@@ -53,8 +53,8 @@ struct orc_prob {
 };
 
 /* a / b, correctly rounded -- the same function as xdiv() in mvolps_amd/csrc/kernels.hip.  On this side the
-   native quotient is already the nearest double and comes back unchanged; the device's fp64 division is one
-   ulp off about once in 1e8 quotients, and the fix-up (exact residual of q and of its neighbour, keep the
+   native quotient is already the nearest double and comes back unchanged; the device's fp64 division can be one
+   ulp off when the quotient lies very close to the midpoint of two doubles, and the fix-up (exact residual of q and of its neighbour, keep the
    smaller) makes both sides return the correctly rounded quotient. */
 static inline double xdiv(double a, double b) {
   const double q = a / b;

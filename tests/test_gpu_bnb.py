@@ -158,7 +158,7 @@ def test_minimisation_ilp_on_gpu(gpu, orc):
 
 
 def test_division_fixup_keeps_a_long_run_bit_exact(gpu, orc):
-    """The fp64 division of the device is one ulp off about once in 1e8 quotients (here:
+    """The fp64 division of the device can be one ulp off when the quotient lies next to a midpoint (here:
     -0x1.6666666666663p-1 / -0x1.ffffffffffffbp-1 in the scaled pivot row of node 634); xdiv() in kernels.hip and in
     the oracle repairs the quotient from its exact residual.  Without it this 641-node run differs from the
     oracle in one event field by one ulp (found by scripts/fuzz.py, seed 98765)."""
