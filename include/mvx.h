@@ -153,9 +153,14 @@ long long mvx_profile_update_launches(void);
 double mvx_last_solve_ms(const mvx_prob *P);
 /* node migration between ranks: image of bounds + basis + tableau in DEVICE
    memory of this process's GPU, ready for an RCCL send; the receiver rebuilds the handle on top of
-   its own copy `base` of the root model (appended cut rows are not carried) */
+   its own copy `base` of the root model.  The `_from` forms also carry the model rows appended since
+   `base` (rows base.m+1 .. m: GMI cut rows, cut.cpp:23-43), so that a node with cuts can migrate; the plain
+   forms carry none and need a receiver `base` with the same number of rows.  The image also carries the
+   tolerances of the solve that produced the status, so a migrated optimal node is not solved again. */
 long long mvx_pack_size(const mvx_prob *P);
 int mvx_pack(const mvx_prob *P, void *dev_buf);
+long long mvx_pack_size_from(const mvx_prob *P, const mvx_prob *base);
+int mvx_pack_from(const mvx_prob *P, const mvx_prob *base, void *dev_buf);
 int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf);
 /* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
    for measurement sweeps -- results are identical for every setting */

@@ -147,6 +147,13 @@ int mvx_bnb_classify(const mvx_lp_api *api, const void *prob, const void *root, 
    create_prob) with the branching bounds set; they are NOT solved here (the caller batches them) */
 int mvx_bnb_make_children(const mvx_lp_api *api, const void *a, int pick, int quirks, void *S2, void *S3);
 
+/* bs.cpp:249-258 on one solved node `a` that is about to be branched: generate its GMI cut(s) and append the
+   row(s) (cut_strat / reference_quirks / lazy_pool / cut_select / cut_chance of `params`).  Returns the number
+   of rows appended.  The pool here holds this node's cuts only; -1 = bug-compatible mode and the node generated
+   no cut, where bs.cpp would re-add the last cut pooled by an earlier node (cut.cpp:16-21) --
+   a branched node has a fractional, hence basic, integer column and therefore always generates one */
+int mvx_bnb_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params *params);
+
 /* ---- callers and data formats either side of the path ---- */
 /* glp_read_lp(prob, NULL, fname) util.cpp:284 -- CPLEX LP format; 0 on success */
 int mvx_read_lp(mvx_prob *P, const void *parm, const char *fname);

@@ -26,6 +26,8 @@ _EXTRA = {
     "simplex_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "pack_size": (C.c_longlong, [C.c_void_p]),
     "pack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pack_size_from": (C.c_longlong, [C.c_void_p, C.c_void_p]),
+    "pack_from": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

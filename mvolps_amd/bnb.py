@@ -96,6 +96,8 @@ def _bind(lib):
     lib.mvx_bnb_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.mvx_bnb_make_children.restype = C.c_int
     lib.mvx_bnb_make_children.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.mvx_bnb_node_cuts.restype = C.c_int
+    lib.mvx_bnb_node_cuts.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BnbParams)]
     lib.mvx_generateCut3.restype = C.c_int
     lib.mvx_generateCut3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return lib
@@ -134,17 +136,23 @@ def result_to_dict(res):
     }
 
 
-def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, lazy_pool=1, table=None, window=None,
-                     cut_select=0, cut_chance=1.0):
-    """Run the driver on `prob` (a capi.Prob).  table=None uses the gfx950 engine's own table."""
-    L = lib()
+def make_params(var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, lazy_pool=1, window=None, cut_select=0, cut_chance=1.0):
+    """mvx_bnb_params with ParameterObj's defaults (util.h:65-67) overridden by the arguments."""
     pr = BnbParams()
-    L.mvx_bnb_default_params(C.byref(pr))
+    lib().mvx_bnb_default_params(C.byref(pr))
     pr.var_strat, pr.node_strat, pr.cut_strat, pr.max_nodes = var_strat, node_strat, cut_strat, max_nodes
     pr.reference_quirks, pr.lazy_pool = quirks, lazy_pool
     pr.cut_select, pr.cut_chance = cut_select, cut_chance
     if window is not None:
         pr.window = window
+    return pr
+
+
+def branch_and_bound(prob, var_strat=0, node_strat=0, cut_strat=0, max_nodes=0, quirks=1, lazy_pool=1, table=None, window=None,
+                     cut_select=0, cut_chance=1.0):
+    """Run the driver on `prob` (a capi.Prob).  table=None uses the gfx950 engine's own table."""
+    L = lib()
+    pr = make_params(var_strat, node_strat, cut_strat, max_nodes, quirks, lazy_pool, window, cut_select, cut_chance)
     res = BnbResult()
     tptr = C.cast(C.pointer(table), C.c_void_p) if table is not None else None
     L.mvx_branchAndBound(tptr, prob.h, C.byref(pr), C.byref(res))
@@ -178,6 +186,14 @@ def generate_cut3(prob, j, table=None):
     if rc != 0:
         return None
     return inds, vals, lb.value
+
+
+def node_cuts(a, params, table=None):
+    """bs.cpp:249-258 on one solved node about to be branched: append its GMI cut row(s); returns their number
+    (-1: bug-compatible mode and the node generated none).  `params`: keyword arguments of make_params."""
+    pr = make_params(**params)
+    tptr = C.cast(C.pointer(table), C.c_void_p) if table is not None else None
+    return lib().mvx_bnb_node_cuts(tptr, a.h, C.byref(pr))
 
 
 def classify(prob, root, quirks=1, var_strat=0, table=None):

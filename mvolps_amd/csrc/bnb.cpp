@@ -378,8 +378,9 @@ void pack_result(mvx_bnb_result *res, const Recorder &rec, int id, int count, in
 // Cut step of a branching node (bs.cpp:249-258), shared by both drivers: bug-compatible mode feeds the
 // persistent pool and appends its last cut (cut.cpp:16-21); repaired mode appends this node's own GMI cuts,
 // chosen by cut_select / -cf.
-static void add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &prm, bool quirks, CutPool &pool) {
-  if (prm.cut_strat == 0) return;
+// Returns the number of rows appended; -1 when the bug-compatible path found its pool empty (nothing generated yet).
+static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &prm, bool quirks, CutPool &pool) {
+  if (prm.cut_strat == 0) return 0;
   if (quirks) {
     const int na = api->get_num_cols(a);
     if (prm.lazy_pool) {
@@ -396,8 +397,7 @@ static void add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &
         if (result.oid != -1) pool.addToPool(std::move(result));
       }
     }
-    pool.addCutConstraint(a);
-    return;
+    return pool.addCutConstraint(a) < 0 ? -1 : 1;
   }
   const int na = api->get_num_cols(a);
   std::vector<CutContainer> local;
@@ -423,7 +423,7 @@ static void add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &
       }
     }
   }
-  if (local.empty()) return;
+  if (local.empty()) return 0;
   int take = 1;
   if (prm.cut_select == 1) {
     take = (int)std::ceil(prm.cut_chance * (double)local.size());
@@ -442,6 +442,7 @@ static void add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &
     api->set_mat_row(a, index, (int)cc.inds.size() - 1, cc.inds.data(), cc.vals.data());
     api->set_row_bnds(a, index, MVX_LO, cc.lb, 0);
   }
+  return take;
 }
 
 int branchAndBound(const mvx_lp_api *api, void *prob, const mvx_bnb_params &prm, mvx_bnb_result *res) { // bs.cpp:54
@@ -982,6 +983,12 @@ int mvx_bnb_make_children(const mvx_lp_api *api, const void *a, int pick, int qu
       api->set_col_bnds(S3, pick, MVX_LO, std::ceil(bound), 0);
   }
   return 0;
+}
+
+int mvx_bnb_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params *params) {
+  if (!api) api = &g_hip_api;
+  CutPool pool(api); // this node's cuts only: a caller that needs bs.cpp:73's pool across nodes keeps the order itself
+  return add_node_cuts(api, a, *params, params->reference_quirks != 0, pool);
 }
 
 int mvx_printInfo(const mvx_lp_api *api, const void *prob, int quirks, int *violated, int *nviolated) {

@@ -406,8 +406,10 @@ int mvx_get_basis(const mvx_prob *P, int *head, int *nb, int *flag) {
 
 int mvx_device_count(void) { return mvx::device_count(); }
 int mvx_set_device(int dev) { return mvx::set_device(dev); }
-long long mvx_pack_size(const mvx_prob *P) { return mvx::engine_pack_size(P); }
-int mvx_pack(const mvx_prob *P, void *dev_buf) { return mvx::engine_pack(P, dev_buf); }
+long long mvx_pack_size(const mvx_prob *P) { return mvx::engine_pack_size(P, P->m); }
+int mvx_pack(const mvx_prob *P, void *dev_buf) { return mvx::engine_pack(P, P->m, dev_buf); }
+long long mvx_pack_size_from(const mvx_prob *P, const mvx_prob *base) { return mvx::engine_pack_size(P, base ? base->m : P->m); }
+int mvx_pack_from(const mvx_prob *P, const mvx_prob *base, void *dev_buf) { return mvx::engine_pack(P, base ? base->m : P->m, dev_buf); }
 int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
   if (dst == base) return -1;
   // model rows / objective / kinds come from the receiver's own copy of the root problem

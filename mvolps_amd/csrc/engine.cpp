@@ -1223,22 +1223,29 @@ int engine_get_row(const mvx_prob *P, int row, double *out) {
 
 // ------------------------------------------------------------------ pack / unpack (migration)
 // Device-side image of a handle for node migration between ranks:
-//   [PackHdr][ctype,rtype,bvar,nvar,nflag i32][clb,cub,rlb,rub f64] pad 256 | T live rows | slab tail
+//   [PackHdr][ctype,rtype,bvar,nvar,nflag i32][clb,cub,rlb,rub f64][model rows m_base+1..m, n+1 f64 each] pad 256
+//   | T live rows | slab tail
+// Rows 1..m_base of the model are the receiver's own (its copy of the root problem); the rows appended since
+// (GMI cut rows, cut.cpp:23-43) travel densely with the image.
 struct PackHdr {
-  long long magic, m, n, ld, m_cap, status, it_cnt, valid, hint_dual, host_bytes, reserved[2];
+  long long magic, m, n, ld, m_cap, status, it_cnt, valid, hint_dual, host_bytes, m_base, reserved;
+  double last_tol[3];
+  double pad_;
 };
-static const long long PACK_MAGIC = 0x4d56584849504bll;
+static const long long PACK_MAGIC = 0x4d56584849504cll;
 
-static size_t pack_host_bytes(int m, int n) {
+static size_t pack_host_bytes(int m, int n, int m_base) {
   size_t sz = sizeof(PackHdr);
   sz += sizeof(int) * ((size_t)(n + 1) + 2 * (size_t)(m + 1) + 2 * (size_t)(n + 1));
   sz = align_up(sz, 8);
   sz += sizeof(double) * (2 * (size_t)(n + 1) + 2 * (size_t)(m + 1));
+  sz += sizeof(double) * (size_t)(m - m_base) * (size_t)(n + 1);
   return align_up(sz, 256);
 }
 
-long long engine_pack_size(const mvx_prob *P) {
-  size_t sz = pack_host_bytes(P->m, P->n);
+long long engine_pack_size(const mvx_prob *P, int m_base) {
+  if (m_base < 0 || m_base > P->m) return -1;
+  size_t sz = pack_host_bytes(P->m, P->n, m_base);
   if (P->valid) {
     SlabLayout L = slab_layout(P->m_cap, P->ld);
     sz += align_up((size_t)(P->m + 1) * P->ld * 8, 256) + (L.total - L.o_bvar);
@@ -1246,17 +1253,18 @@ long long engine_pack_size(const mvx_prob *P) {
   return (long long)sz;
 }
 
-int engine_pack(const mvx_prob *P, void *dev_buf) {
+int engine_pack(const mvx_prob *P, int m_base, void *dev_buf) {
+  if (m_base < 0 || m_base > P->m) return -1;
   Context &c = ctx();
   SolveCtx &sc = c.main;
-  (void)sc;
   const int m = P->m, n = P->n;
-  const size_t hb = pack_host_bytes(m, n);
+  const size_t hb = pack_host_bytes(m, n, m_base);
   std::vector<unsigned char> host(hb, 0);
   unsigned char *b = host.data();
   PackHdr h{};
   h.magic = PACK_MAGIC; h.m = m; h.n = n; h.ld = P->ld; h.m_cap = P->m_cap; h.status = P->status;
-  h.it_cnt = P->it_cnt; h.valid = P->valid; h.hint_dual = P->hint_dual; h.host_bytes = (long long)hb;
+  h.it_cnt = P->it_cnt; h.valid = P->valid; h.hint_dual = P->hint_dual; h.host_bytes = (long long)hb; h.m_base = m_base;
+  std::memcpy(h.last_tol, P->last_tol, sizeof(h.last_tol));
   std::memcpy(b, &h, sizeof(h));
   b += sizeof(h);
   unsigned char *b0 = b;
@@ -1274,6 +1282,7 @@ int engine_pack(const mvx_prob *P, void *dev_buf) {
   put(P->cub.data(), 8 * (size_t)(n + 1));
   put(P->rlb.data(), 8 * (size_t)(m + 1));
   put(P->rub.data(), 8 * (size_t)(m + 1));
+  for (int i = m_base + 1; i <= m; i++) put(P->A[(size_t)i]->data(), 8 * (size_t)(n + 1));
   unsigned char *d = (unsigned char *)dev_buf;
   HIPCHECK(hipMemcpyAsync(d, host.data(), hb, hipMemcpyHostToDevice, sc.stream));
   if (P->valid) {
@@ -1287,17 +1296,17 @@ int engine_pack(const mvx_prob *P, void *dev_buf) {
   return 0;
 }
 
-// dst must already hold a copy of the receiver's root MODEL (rows, objective, kinds)
+// dst already holds a copy of the receiver's root MODEL (rows 1..m_base, objective, kinds); the appended rows,
+// bounds, basis and tableau come from the image
 int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   Context &c = ctx();
   SolveCtx &sc = c.main;
-  (void)sc;
   const unsigned char *d = (const unsigned char *)dev_buf;
   PackHdr h;
   HIPCHECK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
-  if (h.magic != PACK_MAGIC || h.m != dst->m || h.n != dst->n) return -1;
-  const int m = (int)h.m, n = (int)h.n;
+  if (h.magic != PACK_MAGIC || h.m_base != dst->m || h.n != dst->n || h.m < h.m_base) return -1;
+  const int m = (int)h.m, n = (int)h.n, m_base = (int)h.m_base;
   std::vector<unsigned char> host((size_t)h.host_bytes);
   HIPCHECK(hipMemcpyAsync(host.data(), d, (size_t)h.host_bytes, hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
@@ -1307,6 +1316,11 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
     if (dstp) std::memcpy(dstp, b, bytes);
     b += bytes;
   };
+  dst->m = m;
+  dst->A.resize((size_t)m + 1);
+  dst->rtype.resize((size_t)m + 1);
+  dst->rlb.resize((size_t)m + 1);
+  dst->rub.resize((size_t)m + 1);
   get(dst->ctype.data(), sizeof(int) * (n + 1));
   get(dst->rtype.data(), sizeof(int) * (m + 1));
   if (h.valid) {
@@ -1322,15 +1336,22 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   get(dst->cub.data(), 8 * (size_t)(n + 1));
   get(dst->rlb.data(), 8 * (size_t)(m + 1));
   get(dst->rub.data(), 8 * (size_t)(m + 1));
+  for (int i = m_base + 1; i <= m; i++) {
+    auto row = std::make_shared<std::vector<double>>((size_t)n + 1, 0.0);
+    get(row->data(), 8 * (size_t)(n + 1));
+    dst->A[(size_t)i] = row;
+  }
   dst->status = (int)h.status;
   dst->it_cnt = (int)h.it_cnt;
   dst->hint_dual = h.hint_dual != 0;
+  std::memcpy(dst->last_tol, h.last_tol, sizeof(dst->last_tol));
   dst->sol_fresh = false;
   release_device(dst);
   dst->valid = false;
   if (h.valid) {
     SlabLayout L = slab_layout((int)h.m_cap, (int)h.ld);
     void *slab = slab_alloc(c, L.total);
+    if (!slab) return -2;
     bind_slab(dst, slab, (int)h.m_cap, (int)h.ld);
     const size_t tb = (size_t)(m + 1) * dst->ld * 8;
     HIPCHECK(hipMemcpyAsync(dst->d_T, d + h.host_bytes, tb, hipMemcpyDeviceToDevice, sc.stream));

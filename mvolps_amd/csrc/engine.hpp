@@ -27,8 +27,8 @@ void refresh_solution(const mvx_prob *P);
 int engine_get_tableau(const mvx_prob *P, double *out);
 int engine_get_row(const mvx_prob *P, int row, double *out); // out[0..n]
 
-long long engine_pack_size(const mvx_prob *P);
-int engine_pack(const mvx_prob *P, void *dev_buf);
+long long engine_pack_size(const mvx_prob *P, int m_base);
+int engine_pack(const mvx_prob *P, int m_base, void *dev_buf);
 int engine_unpack(mvx_prob *dst, const void *dev_buf);
 void tuning(int tr, int hot, int nt);
 void set_stall_limit(int limit);

@@ -13,15 +13,23 @@ exactly the front W of the deque whatever their outcome.  Each round therefore
   A. solves the front window in parallel (owner ranks), MAX-all-reduces (status, objective, ...);
   B. replays the serial decisions in queue order on every rank (incumbent updated in that order),
      which fixes the branch list and the child oids;
-  C. lets the owners create and solve the children (bs.cpp:269-288), MAX-all-reduces their bounds;
-  D. deals the children round-robin over the ranks; a child that lands on another rank is
-     migrated as a device image of its bounds + basis + tableau (mvx_pack / mvx_unpack) by an
-     RCCL send/recv -- a bitwise copy, so its later arithmetic is the serial run's.
+  C. lets the owners append their nodes' GMI cut rows (bs.cpp:249-258), create and solve the children
+     (bs.cpp:269-288), MAX-all-reduces their bounds;
+  D. gives every child an owner.  Ownership does not affect the result, so a child STAYS on its parent's
+     rank -- its tableau is already there -- unless that rank's share of the window the child will be popped
+     in is full: every future window (W = world x per_rank consecutive queue positions, known exactly under
+     FIFO order) takes at most per_rank nodes per rank, and while the whole queue still fits one window the
+     nodes are spread evenly.  Only a child that has to change ranks is migrated, as a device image of its
+     bounds + basis + tableau + appended cut rows (mvx_pack_from / mvx_unpack) through an RCCL send/recv -- a
+     bitwise copy, so its later arithmetic is the serial run's.  `result["dist"]` reports children, migrated
+     images and bytes (dealing children round-robin, as round 1 did, migrates (N-1)/N of all children).
 Tree, oids, prune labels, events and the incumbent come out identical to the serial driver
 (mvx_branchAndBound); tests/test_dist_bnb.py asserts that with world_size 2.
 
-Best-bound order (util.cpp:170-186) picks by fresh child bounds and is not window-batchable; GMI
-cut rows are not carried by migration.  Both stay on the single-GPU driver.
+Best-bound order (util.cpp:170-186) picks by fresh child bounds and is not window-batchable; it stays on the
+single-GPU driver.  Bug-compatible cuts: bs.cpp:73's pool persists across nodes, but the only cut ever appended
+is the pool's last (cut.cpp:20), which is the branching node's own whenever it generates one -- and a branched
+node always does (its fractional integer column is basic); the coordinator raises if that ever fails.
 """
 from collections import deque
 
@@ -79,11 +87,17 @@ class HipNodeEngine:
         arr = (C.c_void_p * len(probs))(*[p.h for p in probs])
         self.api.simplex_batch(arr, len(probs), None, None)
 
-    def pack(self, prob):
-        n = self.api.pack_size(prob.h)
+    def node_cuts(self, a, params):
+        return self._bnb.node_cuts(a, params, table=self.table)
+
+    def pack_size(self, prob, base):
+        return self.api.pack_size_from(prob.h, base.h)
+
+    def pack(self, prob, base):
+        n = self.api.pack_size_from(prob.h, base.h)
         t = torch.empty(n, dtype=torch.uint8, device=self.device)
-        if self.api.pack(prob.h, t.data_ptr()) != 0:
-            raise RuntimeError("mvx_pack failed")
+        if self.api.pack_from(prob.h, base.h, t.data_ptr()) != 0:
+            raise RuntimeError("mvx_pack_from failed")
         return t.to(self.comm_device)
 
     def recv_buffer(self, nbytes):
@@ -105,11 +119,17 @@ class _Node:
         self.oid, self.owner, self.upper, self.inital = oid, owner, upper, inital
 
 
-def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limit=200000, per_rank=1, group=None):
+def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limit=200000, per_rank=1, group=None,
+                     cut_strat=0, lazy_pool=1, cut_select=0, cut_chance=1.0, deal="owner", slack=None):
     """Serial-equivalent FIFO branch-and-bound over all ranks of `group`.
 
     `root` is this rank's handle of the (identical) root problem.  Returns the same dictionary as
-    mvolps_amd.bnb.branch_and_bound, identical on every rank.
+    mvolps_amd.bnb.branch_and_bound, identical on every rank, plus `dist` (migration statistics).
+    deal="owner": children stay on their parent's rank unless its share of their window is full (default);
+    deal="roundrobin": round 1's dealing, kept to measure the migrated-bytes ratio against.
+    slack: how many nodes beyond per_rank a rank may hold in one window before a child is sent away (default
+    per_rank // 4, at least 1): moving a tableau costs about as much as solving the node, so a little imbalance
+    is cheaper than the traffic that would remove it.
     """
     import torch.distributed as dist
 
@@ -140,6 +160,16 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
     count, hit_limit, total_pivots = 0, 0, 0
     n0 = root.n
     stop_all = False
+    W_full = world * per_rank
+    if slack is None:
+        slack = max(1, per_rank // 4)
+    round_no = 0
+    win_load = {}  # absolute window number -> nodes per rank already placed in it
+    stats = {"world": world, "per_rank": per_rank, "deal": deal, "slack": slack, "children": 0, "migrated": 0, "migrated_bytes": 0, "rounds": 0}
+    cut_params = None
+    if cut_strat:
+        cut_params = dict(var_strat=var_strat, cut_strat=cut_strat, quirks=quirks, lazy_pool=lazy_pool, cut_select=cut_select,
+                          cut_chance=cut_chance)
 
     while queue and not stop_all:
         if max_nodes > 0 and count >= max_nodes:
@@ -230,30 +260,70 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
             if nd.owner != rank:
                 continue
             a = solved[nd.oid]
+            if cut_params is not None and engine.node_cuts(a, cut_params) < 0:  # bs.cpp:249-258
+                raise RuntimeError("node %d generated no cut: bs.cpp would re-add a cut pooled by an earlier node "
+                                   "(cut.cpp:16-21), which the coordinator does not carry between ranks" % nd.oid)
             S2, S3 = engine.make_children(a, pick, quirks)  # bs.cpp:261-282
             made.append((k, s2, s3, S2, S3, S2.it_cnt, S3.it_cnt))
         # every child of this round is an independent LP (bs.cpp:279,287): solve them together
         engine.solve_many([p for (_, _, _, S2, S3, _, _) in made for p in (S2, S3)])
         for k, s2, s3, S2, S3, b2, b3 in made:
-            C[k] = torch.tensor([S2.obj, S3.obj, float((S2.it_cnt - b2) + (S3.it_cnt - b3)), float(api.pack_size(S2.h))], dtype=torch.float64)
+            C[k] = torch.tensor([S2.obj, S3.obj, float((S2.it_cnt - b2) + (S3.it_cnt - b3)), float(engine.pack_size(S2, root))], dtype=torch.float64)
             fresh[s2], fresh[s3] = S2, S3
         C = allreduce_max(C.to(cdev))
 
-        # ---- D. publish the children, deal them round-robin, migrate where needed
+        # ---- D. publish the children, give each an owner, migrate the ones that change ranks
         sends, recvs = [], []
+        base = len(queue) - processed  # nodes that stay queued after this round's pops
+        n_kids = 2 * len(branch_list)
+        spread_cap = -(-(base + n_kids) // world) if base + n_kids <= W_full else None  # whole queue fits one window
+        # Which children leave their parent's rank.  Per future window (rounds pop W_full nodes each from the front,
+        # so a child's window follows from its queue position) and per parent rank: the children beyond that rank's
+        # remaining share are taken EVENLY out of the run, not off its tail.  Under FIFO order a node's children
+        # sit side by side, so ranks own runs of consecutive queue positions that double every level; thinning a
+        # run evenly interleaves the ranks again, and the doubled runs of the next levels fit their windows.
+        kid_owner = []
+        if deal != "roundrobin":
+            groups = {}
+            for k, (nd, s2, s3, pick, ev) in enumerate(branch_list):
+                for t in range(2):
+                    kn = 2 * k + t
+                    wno = round_no + 1 + (base + kn) // W_full
+                    groups.setdefault((wno, nd.owner), []).append(kn)
+                    kid_owner.append(nd.owner)
+            movers = []
+            for (wno, r), kids in sorted(groups.items()):
+                load = win_load.setdefault(wno, [0] * world)
+                cap = spread_cap if spread_cap is not None else per_rank + slack
+                keep = max(0, min(len(kids), cap - load[r]))
+                move = len(kids) - keep
+                load[r] += keep
+                for t in range(move):  # evenly spaced positions of the run
+                    movers.append((kids[(2 * t + 1) * len(kids) // (2 * move)], wno))
+            for kn, wno in sorted(movers):
+                load = win_load[wno]
+                dst = min(range(world), key=lambda r: (load[r], r))
+                load[dst] += 1
+                kid_owner[kn] = dst
+        kid_no = 0
         for k, (nd, s2, s3, pick, ev) in enumerate(branch_list):
             ub2, ub3, piv, nbytes = float(C[k][0]), float(C[k][1]), int(C[k][2]), int(C[k][3])
             total_pivots += piv
             for oid, ub in ((s2, ub2), (s3, ub3)):
-                owner = child_seq % world
+                owner = child_seq % world if deal == "roundrobin" else kid_owner[kid_no]
                 child_seq += 1
+                kid_no += 1
+                stats["children"] += 1
                 bound[oid] = ub
                 queue.append(_Node(oid, owner, ub))
                 ev.append((EV_CANDIDATE, oid, ub, 0.0, 0, 0))
+                if owner != nd.owner:
+                    stats["migrated"] += 1
+                    stats["migrated_bytes"] += nbytes
                 if nd.owner == rank and owner == rank:
                     local[oid] = fresh[oid]
                 elif nd.owner == rank:
-                    sends.append((oid, owner, engine.pack(fresh[oid])))
+                    sends.append((oid, owner, engine.pack(fresh[oid], root)))
                 elif owner == rank:
                     recvs.append((oid, nd.owner, engine.recv_buffer(nbytes)))
         if world > 1 and (sends or recvs):
@@ -263,6 +333,9 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
                 req.wait()
             for oid, _, t in recvs:
                 local[oid] = engine.unpack(root, t)
+        win_load.pop(round_no, None)
+        round_no += 1
+        stats["rounds"] += 1
         for ev in per_node_events:
             events.extend(ev)
         for _ in range(processed):
@@ -296,4 +369,5 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         "x": [float(v) for v in x.tolist()],
         "total_pivots": total_pivots,
         "hit_limit": hit_limit,
+        "dist": stats,
     }

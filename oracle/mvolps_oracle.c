@@ -1153,25 +1153,29 @@ int orc_get_basis(const orc_prob *P, int *head, int *nb, int *flag) {
 }
 
 /* ------------------------------------------------------------- pack / unpack */
+/* Host-memory counterpart of mvx_pack_from / mvx_unpack (world_size-2 gloo tests run the coordinator over this
+   library): rows 1..m_base of the model are the receiver's own, the rows appended since (cut rows) travel. */
 typedef struct {
-  long long magic, m, n, ld, status, it_cnt, valid, reserved;
+  long long magic, m, n, ld, status, it_cnt, valid, m_base;
 } pack_hdr;
-#define PACK_MAGIC 0x4d56584f5243ll
+#define PACK_MAGIC 0x4d56584f5244ll
 
-long long orc_pack_size(const orc_prob *P) {
+static long long pack_size_from(const orc_prob *P, int m_base) {
   long long m = P->m, n = P->n;
   long long sz = sizeof(pack_hdr);
   sz += (long long)sizeof(int) * ((n + 1) + (m + 1) + (m + 1) + 2 * (n + 1));
   sz = (sz + 7) / 8 * 8;
   sz += (long long)sizeof(double) * (2 * (n + 1) + 2 * (m + 1));
+  sz += (long long)sizeof(double) * (m - m_base) * (n + 1);
   if (P->valid) sz += (long long)sizeof(double) * ((m + 1) * (long long)P->ld + 2 * (m + 1) + 2 * (n + 1));
   return sz;
 }
 
-int orc_pack(const orc_prob *P, void *buf) {
+static int pack_from(const orc_prob *P, int m_base, void *buf) {
   int m = P->m, n = P->n;
+  if (m_base < 0 || m_base > m) return -1;
   unsigned char *b = (unsigned char *)buf;
-  pack_hdr h = {PACK_MAGIC, m, n, P->ld, P->status, P->it_cnt, P->valid, 0};
+  pack_hdr h = {PACK_MAGIC, m, n, P->ld, P->status, P->it_cnt, P->valid, m_base};
   memcpy(b, &h, sizeof(h)); b += sizeof(h);
   unsigned char *b0 = b;
 #define PUT(ptr, cnt, T) do { memcpy(b, (ptr), (size_t)(cnt) * sizeof(T)); b += (size_t)(cnt) * sizeof(T); } while (0)
@@ -1182,6 +1186,7 @@ int orc_pack(const orc_prob *P, void *buf) {
   b = b0 + ((size_t)(b - b0) + 7) / 8 * 8;
   PUT(P->clb, n + 1, double); PUT(P->cub, n + 1, double);
   PUT(P->rlb, m + 1, double); PUT(P->rub, m + 1, double);
+  for (int i = m_base + 1; i <= m; i++) PUT(P->A[i], n + 1, double);
   if (P->valid) {
     PUT(P->T, (size_t)(m + 1) * P->ld, double);
     PUT(P->blb, m + 1, double); PUT(P->bub, m + 1, double);
@@ -1191,19 +1196,25 @@ int orc_pack(const orc_prob *P, void *buf) {
   return 0;
 }
 
+long long orc_pack_size(const orc_prob *P) { return pack_size_from(P, P->m); }
+int orc_pack(const orc_prob *P, void *buf) { return pack_from(P, P->m, buf); }
+long long orc_pack_size_from(const orc_prob *P, const orc_prob *base) { return pack_size_from(P, base ? base->m : P->m); }
+int orc_pack_from(const orc_prob *P, const orc_prob *base, void *buf) { return pack_from(P, base ? base->m : P->m, buf); }
+
 int orc_unpack(orc_prob *dst, const orc_prob *base, const void *buf) {
   const unsigned char *b = (const unsigned char *)buf;
   pack_hdr h;
   memcpy(&h, b, sizeof(h)); b += sizeof(h);
-  if (h.magic != PACK_MAGIC || h.m != base->m || h.n != base->n) return -1;
-  int m = (int)h.m, n = (int)h.n;
-  /* model rows / objective / kinds come from the receiver's copy of the root problem */
+  if (h.magic != PACK_MAGIC || h.m_base != base->m || h.n != base->n || h.m < h.m_base) return -1;
+  int m = (int)h.m, n = (int)h.n, m_base = (int)h.m_base;
+  /* model rows 1..m_base / objective / kinds come from the receiver's copy of the root problem */
   {
     int was_valid = base->valid;
     ((orc_prob *)base)->valid = 0; /* copy the model only */
     orc_copy_prob(dst, base, ORC_ON);
     ((orc_prob *)base)->valid = was_valid;
   }
+  if (m > m_base) orc_add_rows(dst, m - m_base);
   const unsigned char *b0 = b;
 #define GET(ptr, cnt, T) do { memcpy((ptr), b, (size_t)(cnt) * sizeof(T)); b += (size_t)(cnt) * sizeof(T); } while (0)
   GET(dst->ctype, n + 1, int);
@@ -1213,6 +1224,7 @@ int orc_unpack(orc_prob *dst, const orc_prob *base, const void *buf) {
   b = b0 + ((size_t)(b - b0) + 7) / 8 * 8;
   GET(dst->clb, n + 1, double); GET(dst->cub, n + 1, double);
   GET(dst->rlb, m + 1, double); GET(dst->rub, m + 1, double);
+  for (int i = m_base + 1; i <= m; i++) GET(dst->A[i], n + 1, double);
   dst->status = (int)h.status;
   dst->it_cnt = (int)h.it_cnt;
   dst->valid = (int)h.valid;

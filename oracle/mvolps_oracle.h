@@ -137,6 +137,8 @@ int orc_get_basis(const orc_prob *P, int *head, int *nb, int *flag);
    the receiver's base problem; appended cut rows are not carried).  Host memory. */
 long long orc_pack_size(const orc_prob *P);
 int orc_pack(const orc_prob *P, void *buf);
+long long orc_pack_size_from(const orc_prob *P, const orc_prob *base);
+int orc_pack_from(const orc_prob *P, const orc_prob *base, void *buf);
 int orc_unpack(orc_prob *dst, const orc_prob *base, const void *buf);
 
 /* ---- MVOLPS-owned pieces restated on top of the API above ---- */

@@ -81,6 +81,8 @@ def api():
             "generateCutGMI": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
             "pack_size": (C.c_longlong, [C.c_void_p]),
             "pack": (C.c_int, [C.c_void_p, C.c_void_p]),
+            "pack_size_from": (C.c_longlong, [C.c_void_p, C.c_void_p]),
+            "pack_from": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
             "unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
             "bnb_default_params": (None, [C.POINTER(BnbParams)]),
             "branchAndBound": (C.c_int, [C.c_void_p, C.POINTER(BnbParams), C.POINTER(BnbResult)]),

@@ -37,10 +37,16 @@ class OracleNodeEngine:
         for p in probs:
             p.simplex()
 
-    def pack(self, prob):
-        n = self.api.pack_size(prob.h)
+    def node_cuts(self, a, params):
+        return self._bnb.node_cuts(a, params, table=self.table)
+
+    def pack_size(self, prob, base):
+        return self.api.pack_size_from(prob.h, base.h)
+
+    def pack(self, prob, base):
+        n = self.api.pack_size_from(prob.h, base.h)
         buf = np.zeros(n, dtype=np.uint8)
-        assert self.api.pack(prob.h, buf.ctypes.data) == 0
+        assert self.api.pack_from(prob.h, base.h, buf.ctypes.data) == 0
         return torch.from_numpy(buf)
 
     def recv_buffer(self, nbytes):

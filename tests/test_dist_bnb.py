@@ -76,8 +76,63 @@ def test_pack_unpack_roundtrip(orc):
     from mvolps_amd import capi
 
     orc.set_col_bnds(P.h, j, capi.UP, 0.0, float(np.floor(x[j - 1])))
-    Q = eng.unpack(root, eng.pack(P))
+    Q = eng.unpack(root, eng.pack(P, root))
     assert np.array_equal(P.tableau(), Q.tableau())
     P.simplex()
     Q.simplex()
     assert P.it_cnt == Q.it_cnt and np.array_equal(P.tableau(), Q.tableau()) and P.obj == Q.obj
+
+
+def test_pack_carries_appended_cut_rows(orc):
+    """A node with GMI cut rows appended (cut.cpp:23-43) migrates whole: model rows beyond the receiver's root, their
+    bounds, the grown basis and tableau."""
+    eng = dist_helpers.OracleNodeEngine()
+    A, b, c, U = synth.dense_ilp(10, 20, 4, 3)
+    root = lpgen.load_ilp(orc, A, b, c, U)
+    P = root.copy()
+    P.simplex()
+    for quirks in (1, 0):
+        assert eng.node_cuts(P, dict(cut_strat=1, quirks=quirks)) == 1
+    assert P.m == root.m + 2
+    P.simplex()
+    Q = eng.unpack(root, eng.pack(P, root))
+    assert Q.m == P.m and Q.status == P.status
+    assert np.array_equal(P.tableau(), Q.tableau())
+    for i in (P.m - 1, P.m):
+        assert all(np.array_equal(u, v) for u, v in zip(P.get_mat_row(i), Q.get_mat_row(i)))
+        assert orc.get_row_lb(P.h, i) == orc.get_row_lb(Q.h, i) and orc.get_row_type(P.h, i) == orc.get_row_type(Q.h, i)
+    x = P.col_prim()
+    j = [k + 1 for k in range(20) if abs(x[k] - round(x[k])) > 1e-9][0]
+    from mvolps_amd import capi
+
+    for H in (P, Q):
+        orc.set_col_bnds(H.h, j, capi.DB, 0.0, float(np.floor(x[j - 1])))
+        H.simplex()
+    assert P.it_cnt == Q.it_cnt and np.array_equal(P.tableau(), Q.tableau()) and P.obj == Q.obj
+
+
+@pytest.mark.parametrize("kw", [dict(quirks=1, cut_strat=1, max_nodes=300), dict(quirks=0, cut_strat=1), dict(quirks=0, cut_strat=1, cut_select=1, cut_chance=0.4)],
+                         ids=["bugcompat", "repaired", "efficacy"])
+def test_world2_with_gmi_cuts_matches_serial(orc, tmp_path, kw):
+    """Config 3 + config 5 combined: cut rows ride in the migration image, so the cut modes distribute too."""
+    case = (10, 20, 4, 3)
+    A, b, c, U = synth.dense_ilp(*case)
+    serial = canon(bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), table=bnb.table_from(orc), **kw))
+    res = dist_helpers.run_world(2, case, dict(per_rank=2, **kw), str(tmp_path))
+    assert_same(res[0], res[1])
+    assert_same(res[0], serial)
+    assert serial["count"] > 20 and res[0]["dist"]["migrated"] > 0
+
+
+def test_children_stay_with_their_parents_rank(orc, tmp_path):
+    """Ownership does not affect the result, only the traffic: dealing children to the parent's rank (per-window
+    quota) migrates a small share of them; round-robin dealing migrates about half at world size 2."""
+    case = (16, 32, 5, 2)
+    kw = dict(quirks=0, per_rank=16)
+    own = dist_helpers.run_world(2, case, dict(deal="owner", **kw), str(tmp_path))[0]
+    rr = dist_helpers.run_world(2, case, dict(deal="roundrobin", **kw), str(tmp_path))[0]
+    assert_same(own, rr)
+    so, sr = own["dist"], rr["dist"]
+    assert so["children"] == sr["children"] > 4000
+    assert abs(sr["migrated"] / sr["children"] - 0.5) < 0.1
+    assert so["migrated"] < 0.25 * sr["migrated"], (so, sr)

@@ -64,8 +64,9 @@ def test_ilp_optimum_matches_milp_golden(gpu):
     assert abs(r["best_lower"] - 35.0) <= 1e-9 * 35 and np.allclose(r["x"], f1["ilp_x"], atol=1e-8)
 
 
-def test_config3_ilp_512x1024_first_nodes(gpu, orc):
-    """BASELINE config 3 shape (m=512, n=1024, integer data, GMI cuts on): first nodes of the tree."""
+def test_config3_shape_without_cuts_first_nodes(gpu, orc):
+    """BASELINE config 3 shape (m=512, n=1024, integer data) with the reference's default -cm 0 (no cuts), bug-compatible
+    mode: first nodes of the tree.  The cut path at this size is test_config3_cut_path_at_size below."""
     from oracle import oracle
 
     A, b, c, U = synth.dense_ilp(512, 1024, seed=12345, U=3)
@@ -73,6 +74,60 @@ def test_config3_ilp_512x1024_first_nodes(gpu, orc):
     got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), max_nodes=6)
     same_result(got, ref)
     assert got["total_pivots"] > 100
+
+
+_C3_REF = {}
+
+
+def _config3_oracle(orc, quirks, **kw):
+    """One oracle run per mode, shared by the parametrised cases below (0.1 s of CPU per node with cuts)."""
+    from oracle import oracle
+
+    key = (quirks,) + tuple(sorted(kw.items()))
+    if key not in _C3_REF:
+        A, b, c, U = synth.dense_ilp(512, 1024, seed=12345, U=3)
+        _C3_REF[key] = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=quirks, cut_strat=1, **kw)
+    return _C3_REF[key]
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+@pytest.mark.parametrize("lazy_pool,window", [(1, 64), (0, 64), (1, 1)], ids=["lazy-w64", "allcuts-w64", "lazy-serial"])
+def test_config3_cut_path_at_size(gpu, orc, quirks, lazy_pool, window):
+    """BASELINE config 3: ILP 512x1024 with GMI cuts on (-cm 1), 320 nodes of the FIFO tree, against the oracle's
+    restatement of bs.cpp:249-258 + gmi.cpp:11-117 + cut.cpp:11-46 -- bug-compatible (persistent pool, positional
+    back-substitution) and repaired.  Device side: tableau-row read, k_add_rows / k_rowcomb into a spare row of the
+    slab, the children inherit the row and warm-start in the dual simplex; window 64 replays the pool in queue order."""
+    ref = _config3_oracle(orc, quirks, max_nodes=320)
+    A, b, c, U = synth.dense_ilp(512, 1024, seed=12345, U=3)
+    got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=quirks, cut_strat=1, max_nodes=320, lazy_pool=lazy_pool, window=window)
+    same_result(got, ref)
+    assert got["count"] == 320 and got["prune"].count(4) > 300  # a real tree: branchings, hence cuts, all the way
+
+
+def test_deep_cut_rows_cross_the_spare_rows(gpu, orc):
+    """Best-bound order dives: 2500 nodes of a 128x256 ILP with the bug-compatible cut path reach depth 52, one appended
+    cut row per level -- past the 32 spare rows every slab keeps behind row m (ROW_SPARE), so the slab has to grow
+    (grow_rows) under the driver, more than once along a path; the result still equals the oracle's.  (At 512x1024
+    300 best-bound nodes only reach depth 33; the repaired mode crosses the boundary at size in the next test.)"""
+    from oracle import oracle
+
+    from . import treedigest
+
+    A, b, c, U = synth.dense_ilp(128, 256, 7, 3)
+    kw = dict(quirks=1, cut_strat=1, node_strat=1, max_nodes=2500)
+    ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), **kw)
+    assert treedigest.depth(ref) > 40
+    got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), **kw)
+    same_result(got, ref)
+
+
+def test_config3_efficacy_selected_cuts_at_size(gpu, orc):
+    """-cf honoured: the 10 % most effective of each node's GMI cuts are appended, ~9 rows per
+    branching, so depth 4 is already past the spare rows; window 64 against the oracle."""
+    ref = _config3_oracle(orc, 0, cut_select=1, cut_chance=0.1, max_nodes=40)
+    A, b, c, U = synth.dense_ilp(512, 1024, seed=12345, U=3)
+    got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=0, cut_strat=1, cut_select=1, cut_chance=0.1, max_nodes=40)
+    same_result(got, ref)
 
 
 def test_cli_end_to_end_f1(gpu, tmp_path):

@@ -23,7 +23,7 @@ def test_device_pack_unpack_roundtrip(gpu):
     x = P.col_prim()
     j = [k + 1 for k in range(48) if np.trunc(x[k]) != x[k]][0]
     gpu.set_col_bnds(P.h, j, capi.LO, float(np.ceil(x[j - 1])), 0.0)
-    img = eng.pack(P)
+    img = eng.pack(P, root)
     assert img.is_cuda and img.numel() == gpu.pack_size(P.h)
     Q = eng.unpack(root, img)
     assert np.array_equal(P.tableau(), Q.tableau())
