@@ -11,7 +11,11 @@ LP's ~3.4k pivots to optimality carries on with a device-to-device clone of the 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N>1: every rank solves its own LP of the same shape (seed 12345 + rank) -- independent
-subproblems, no data-path collective (weak scaling).  Rank 0 prints ONE JSON line.
+subproblems, no data-path collective (weak scaling).  Rank 0 prints ONE JSON line.  `python bench.py --gpus N`
+without a launcher starts the N ranks itself (torch.distributed.run as a child process, before anything touches
+the GPU); a WORLD_SIZE that disagrees with --gpus is an error -- the line never reports another n_gpus than asked.
+At N>1 the line also carries `secondary.bnb_ilp_512x1024_dist`: the B&B node farm (mvolps_amd/dist_bnb.py,
+/root/reference/bs.cpp:96-327 sharded over the ranks) on the BASELINE config-5 instance over RCCL.
 """
 import argparse
 import json
@@ -134,10 +138,42 @@ def cpu_baseline(m, n, seed, budget_s=9.0, max_pivots=400):
     return out
 
 
-def secondary(api):
+def config5_fixture():
+    """tests/golden/config5.json: the calibrated config-5 instance and the oracle's digests of its tree (data only;
+    None when the file is not there)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "config5.json")))
+    except Exception:
+        return None
+
+
+def config5_instance():
+    from mvolps_amd import synth
+
+    fx = config5_fixture() or {"m": 512, "n": 1024, "seed": 12345, "U": 3.0, "cap": 0.4, "reference_quirks": 0}
+    A, b, c, U = synth.dense_ilp(fx["m"], fx["n"], fx["seed"], fx["U"], fx.get("cap", 0.4))
+    return fx, (A, b, c, U)
+
+
+def bnb_cpu_baseline(inst, quirks, budget_nodes=150):
+    """Oracle restatement of bs.cpp on the oracle's LP engine, same instance, first `budget_nodes` nodes."""
+    from mvolps_amd import synth
+    from oracle import oracle
+
+    threads = min(os.cpu_count() or 1, 16)
+    orc = oracle.api()
+    A, b, c, U = inst
+    t0 = time.perf_counter()
+    r = oracle.branch_and_bound(synth.load_ilp(orc, A, b, c, U), quirks=quirks, max_nodes=budget_nodes)
+    el = time.perf_counter() - t0
+    return {"value": r["count"] / el, "unit": "nodes/s", "cores": threads, "kind": "port", "pivots_per_s": r["total_pivots"] / el,
+            "sample": "first %d nodes of the same FIFO tree, oracle/mvolps_oracle_bnb.c (one node at a time; OpenMP row-parallel "
+                      "pivots, %d threads)" % (r["count"], threads)}
+
+
+def secondary(api, with_cpu=True):
     """Other BASELINE configs on the same GPU, reported beside the headline (not part of `value`)."""
-    from mvolps_amd import bnb, dist_bnb, synth
-    from tests import lpgen
+    from mvolps_amd import bnb, dist_bnb, synth, treedigest
 
     out = {}
     # config 2: dense LP 1024x2048 -- cache-resident, latency-bound (BASELINE.md: report, do not headline)
@@ -147,27 +183,93 @@ def secondary(api):
     P.simplex(it_lim=50)
     api.sync()
     t0 = time.perf_counter()
-    P.simplex(it_lim=800)
+    P.simplex(it_lim=600)
     api.sync()
     el = time.perf_counter() - t0
-    out["dense_lp_1024x2048"] = {"pivots_per_s": 800 / el, "us_per_pivot": el / 800 * 1e6,
-                                 "frac_of_hbm_roofline": 800 / el * bytes_per_pivot(1024, 2048) / 1e9 / HBM_PEAK_GBS}
-    # configs 3/5 shape: ILP 512x1024, FIFO B&B.  mvx_branchAndBound in window mode (64 node LPs share each launch)
-    # and the multi-rank coordinator on one rank (same tree, Python replay of the decisions)
-    A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3)
-    bnb.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=64)  # warm-up
+    out["dense_lp_1024x2048"] = {"pivots_per_s": 600 / el, "us_per_pivot": el / 600 * 1e6,
+                                 "frac_of_hbm_roofline": 600 / el * bytes_per_pivot(1024, 2048) / 1e9 / HBM_PEAK_GBS}
+    # configs 3/5 shape: the calibrated config-5 ILP, FIFO B&B.  mvx_branchAndBound in window mode (64 node LPs share each
+    # launch) and the multi-rank coordinator on one rank (same tree, Python replay of the decisions)
+    fx, inst = config5_instance()
+    A, b, c, U = inst
+    q = int(fx.get("reference_quirks", 0))
+    nodes = 2000
+    bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=64)  # warm-up
     t0 = time.perf_counter()
-    r = bnb.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=2000)
+    r = bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=nodes)
     el = time.perf_counter() - t0
+    want = (fx.get("prefix") or {}).get(str(nodes), {}).get("sha256")
     out["bnb_ilp_512x1024"] = {"driver": "mvx_branchAndBound", "nodes": r["count"], "nodes_per_s": r["count"] / el,
-                               "pivots": r["total_pivots"], "pivots_per_s": r["total_pivots"] / el, "window": 64}
+                               "pivots": r["total_pivots"], "pivots_per_s": r["total_pivots"] / el, "window": 64,
+                               "same_tree_as_oracle_fixture": (treedigest.digest(r) == want) if want else None}
     eng = dist_bnb.HipNodeEngine(0)
     t0 = time.perf_counter()
-    r2 = dist_bnb.branch_and_bound(eng, lpgen.load_ilp(api, A, b, c, U), quirks=0, max_nodes=2000, per_rank=64)
+    r2 = dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=nodes, per_rank=64)
     el = time.perf_counter() - t0
     out["bnb_ilp_512x1024_coordinator"] = {"driver": "mvolps_amd.dist_bnb (1 rank)", "nodes": r2["count"], "nodes_per_s": r2["count"] / el,
                                            "pivots": r2["total_pivots"], "same_tree": r2["prune"] == r["prune"], "per_rank": 64}
+    if with_cpu:
+        out["bnb_ilp_512x1024"]["cpu_baseline"] = bnb_cpu_baseline(inst, q)
     return out
+
+
+def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes):
+    """secondary.bnb_ilp_512x1024_dist (every rank calls this): the serial-equivalent node farm over the process
+    group -- node LPs sharded over the ranks (bs.cpp:96-327), MAX all-reduces for the incumbent and the child bounds,
+    RCCL send/recv for the children that change ranks."""
+    import torch
+
+    from mvolps_amd import dist_bnb, synth, treedigest
+
+    fx, inst = config5_instance()
+    A, b, c, U = inst
+    q = int(fx.get("reference_quirks", 0))
+    eng = dist_bnb.HipNodeEngine(dev_index, comm_device="cpu" if rehearsal else None)
+    dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=4 * world * 16, per_rank=16)  # warm-up
+    out = {}
+    for deal in ("owner", "roundrobin"):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=nodes, per_rank=64, deal=deal)
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        st = r["dist"]
+        want = (fx.get("prefix") or {}).get(str(nodes), {}).get("sha256")
+        out[deal] = {"nodes": r["count"], "nodes_per_s": r["count"] / el, "pivots": r["total_pivots"], "seconds": el,
+                     "children": st["children"], "migrated_images": st["migrated"], "migrated_share": st["migrated"] / max(1, st["children"]),
+                     "migrated_bytes_per_node": st["migrated_bytes"] / max(1, r["count"]), "rounds": st["rounds"],
+                     "same_tree_as_oracle_fixture": (treedigest.digest(r) == want) if want else None}
+    res = out["owner"]
+    res["driver"] = "mvolps_amd.dist_bnb"
+    res["ranks"] = world
+    res["per_rank"] = 64
+    res["collective"] = {"backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL over xGMI)", "ranks": world,
+                         "ops_per_round": "2 MAX all-reduces + send/recv of migrated node images"}
+    res["roundrobin_dealing"] = {k: out["roundrobin"][k] for k in ("nodes_per_s", "migrated_images", "migrated_share", "migrated_bytes_per_node")}
+    return res
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child process tree
+    (torch.distributed.run), before this process has touched the GPU, and leave with its exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MVX_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -181,22 +283,36 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements of configs 2 and 3/5")
     ap.add_argument("--profile-steps", type=int, default=200, help="extra pivots timed per-kernel with HIP events")
+    ap.add_argument("--bnb-nodes", type=int, default=3000, help="nodes of the config-5 tree the distributed B&B leg runs (N>1)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    # rehearsal on a one-GPU box only: MVX_BENCH_REHEARSAL=1 puts every rank on device 0 and uses
+    # gloo for the barrier / MAX-reduce, to exercise the multi-rank code path without N GPUs
+    rehearsal = os.environ.get("MVX_BENCH_REHEARSAL") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one.  Nothing here initialises the GPU (torch.cuda.device_count() only counts devices).
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus and not rehearsal:
+            raise SystemExit("--gpus %d asked for, %d HIP device(s) visible (MVX_BENCH_REHEARSAL=1 rehearses the %d-rank path "
+                             "on one GPU over gloo)" % (args.gpus, have, args.gpus))
+        raise SystemExit(self_launch(args))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...`, or run `python bench.py --gpus %d` alone"
+                         % (world, args.gpus, args.gpus, args.gpus, args.gpus))
     import mvolps_amd
 
     mvolps_amd.require_device()
     api = mvolps_amd.api()
-    # rehearsal on a one-GPU box only: MVX_BENCH_REHEARSAL=1 puts every rank on device 0 and uses
-    # gloo for the barrier / MAX-reduce, to exercise the multi-rank code path without N GPUs
-    rehearsal = os.environ.get("MVX_BENCH_REHEARSAL") == "1"
     dev_index = 0 if rehearsal else local_rank
     if api.set_device(dev_index) != 0:
         raise SystemExit("cannot bind device %d" % dev_index)
@@ -290,6 +406,13 @@ def main():
                 "bytes_per_launch": bytes_per_pivot(m, n),
             }
 
+    dist_leg = None
+    if dist is not None and world > 1:
+        try:
+            dist_leg = dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, args.bnb_nodes)
+        except Exception as e:  # every rank raises or none does (the failure modes are deterministic: fixture, engine)
+            dist_leg = {"error": repr(e)}
+
     out = None
     if rank == 0:
         value = world * args.steps / el_max
@@ -316,12 +439,16 @@ def main():
             "pivot_roofline_frac": (args.steps / el_max) * bytes_per_pivot(m, n) / 1e9 / HBM_PEAK_GBS,
             "device_ms_per_step": device_ms / args.steps,
             "roofline": roof,
+            "collective": None if dist is None else {"backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL over xGMI)",
+                                                     "ranks": world, "data_path": "none: independent LPs (barrier + MAX of the wall time only)"},
         }
         if world == 1 and not args.no_secondary:
             try:
-                out["secondary"] = secondary(api)
+                out["secondary"] = secondary(api, with_cpu=not args.no_cpu_baseline)
             except Exception as e:  # the headline line must not depend on the side measurements
                 out["secondary"] = {"error": str(e)}
+        if dist_leg is not None:
+            out["secondary"] = {"bnb_ilp_512x1024_dist": dist_leg}
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(m, n, args.seed)
         print(json.dumps(out), flush=True)

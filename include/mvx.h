@@ -52,6 +52,8 @@ extern "C" {
 /* mvx_simplex return codes (glp_simplex) */
 #define MVX_EFAIL 5
 #define MVX_EITLIM 8
+/* mvx_last_error codes */
+#define MVX_ENOMEM 0x101 /* the device ran out of memory for a tableau slab */
 
 typedef struct mvx_prob mvx_prob; /* replaces glp_prob */
 
@@ -88,6 +90,13 @@ int mvx_load_dense(mvx_prob *P, int m, int n, const double *A, const double *b, 
 
 /* ---- solve -------------------------------------------------------------------- */
 void mvx_init_smcp(mvx_smcp *parm);                /* glp_init_smcp */
+/* Tolerances used when `parm` is NULL (every glp_simplex call of MVOLPS passes NULL: bs.cpp:117,279,287) and filled in
+   by mvx_init_smcp.  Engine defaults: tol_bnd = tol_dj = tol_piv = 1e-9.  GLPK's defaults are tol_bnd = tol_dj = 1e-7,
+   tol_piv = 1e-9 [GLPK-recalled]; they are tighter here so that objectives meet 1e-9 relative against independent
+   solvers.  Where it matters to MVOLPS: util.cpp:443 tests integrality with no tolerance, so a primal value the
+   tolerance lets stop short of its bound by 1e-8 reads as fractional -- the tighter value makes that rarer, not
+   different in kind.  A caller that wants GLPK's numbers calls mvx_set_default_tolerances(1e-7, 1e-7, 1e-9) once. */
+void mvx_set_default_tolerances(double tol_bnd, double tol_dj, double tol_piv);
 int mvx_simplex(mvx_prob *P, const mvx_smcp *parm); /* glp_simplex bs.cpp:117,279,287;
                                                        BranchAndBound.cpp:52,134,141 */
 
@@ -169,6 +178,13 @@ void mvx_set_tuning(int tr, int hot, int nt);
 void mvx_set_batch_slots(int slots);
 /* block until all work queued on the engine stream has finished */
 void mvx_sync(void);
+/* Device out-of-memory never aborts: a solve that cannot get its tableau returns MVX_EFAIL (status MVX_UNDEF), a clone
+   that cannot get one keeps the model only, a row append that cannot grow its slab drops the tableau (the next solve
+   restarts from the slack basis) -- and this call reads MVX_ENOMEM once (0 = nothing happened since the last call).
+   Threads: callers use one host thread at a time per handle (GLPK's contract); the engine itself is safe for the one
+   split mvx_branchAndBound makes -- batch solves on a worker thread while the calling thread clones, edits, queries
+   and deletes OTHER handles. */
+int mvx_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ SIGNATURES = {
     "set_col_name": (None, [_P, _I, C.c_char_p]),
     "load_dense": (_I, [_P, _I, _I, _DP, _DP, _DP]),
     "init_smcp": (None, [C.POINTER(Smcp)]),
+    "set_default_tolerances": (None, [_D, _D, _D]),
     "simplex": (_I, [_P, C.POINTER(Smcp)]),
     "get_obj_dir": (_I, [_P]),
     "get_num_rows": (_I, [_P]),

@@ -235,13 +235,26 @@ int mvx_load_dense(mvx_prob *P, int m, int n, const double *A, const double *b, 
   return 0;
 }
 
+// Tolerances behind `parm == NULL` / mvx_init_smcp.  GLPK's own defaults are 1e-7 / 1e-7 / 1e-9 [GLPK-recalled]; this
+// engine's are 1e-9 throughout so that the objective of the dense LPs meets 1e-9 relative against the HiGHS goldens
+// (a reduced cost of 5e-8 left un-entered moves the optimum by more than that).  mvx_set_default_tolerances puts
+// GLPK's values (or any others) behind every NULL-parameter call, which is all MVOLPS ever makes (bs.cpp:117,279,287).
+static double g_tol_bnd = 1e-9, g_tol_dj = 1e-9, g_tol_piv = 1e-9;
+
+void mvx_set_default_tolerances(double tol_bnd, double tol_dj, double tol_piv) {
+  if (!(tol_bnd > 0.0) || !(tol_dj > 0.0) || !(tol_piv > 0.0)) fault("set_default_tolerances: tolerances must be positive");
+  g_tol_bnd = tol_bnd;
+  g_tol_dj = tol_dj;
+  g_tol_piv = tol_piv;
+}
+
 void mvx_init_smcp(mvx_smcp *parm) {
   parm->msg_lev = 0;
   parm->meth = 1;
   parm->it_lim = -1;
-  parm->tol_bnd = 1e-9;
-  parm->tol_dj = 1e-9;
-  parm->tol_piv = 1e-9;
+  parm->tol_bnd = g_tol_bnd;
+  parm->tol_dj = g_tol_dj;
+  parm->tol_piv = g_tol_piv;
 }
 
 int mvx_simplex(mvx_prob *P, const mvx_smcp *parm) { return mvx::engine_simplex(P, parm); }
@@ -430,5 +443,6 @@ double mvx_profile_update_ms(void) { return mvx::profile_update_ms(); }
 long long mvx_profile_update_launches(void) { return mvx::profile_update_launches(); }
 double mvx_last_solve_ms(const mvx_prob *P) { return P->last_ms; }
 void mvx_sync(void) { mvx::sync_stream(); }
+int mvx_last_error(void) { return mvx::take_last_error(); }
 
 } // extern "C"

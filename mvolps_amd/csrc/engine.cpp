@@ -8,9 +8,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <tuple>
-#include <unordered_set>
+#include <unordered_map>
 #include <vector>
 
 #include "engine.hpp"
@@ -72,29 +74,48 @@ struct SolveCtx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
 };
 
+// Slabs carved out of one multi-slab allocation (a growing B&B tree asks for one slab per open node: hipMalloc
+// costs ~60 us a call, a chunk of up to 32 amortises it).  An arena goes back to the driver only whole, when every
+// slab of it is idle.
+struct Arena {
+  void *base = nullptr;
+  size_t slab_bytes = 0;
+  int count = 0, idle = 0;
+};
+
+// Slab recycling (B&B clones come and go at one size).  Shared by the calling thread and the B&B driver's worker
+// thread (bnb.cpp: child solves run on a worker while the caller clones and deletes other handles), hence the lock.
+struct SlabCache {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_slabs;
+  std::unordered_map<void *, int> arena_of; // slab -> index into arenas
+  std::vector<Arena> arenas;
+  size_t idle_bytes = 0; // bytes held by idle slabs, arena slabs included
+};
+
 struct Context {
   int dev = -1;
   bool aux_ready = false;
+  // every entry point that works on the main context (its stream, control block, scratch, staging buffer) holds
+  // this lock: single-handle solves, model edits, clones, queries that refresh the mirrors
+  std::recursive_mutex main_mu;
   SolveCtx main;
   // single-handle solves issued from inside a batch call (a lone pending handle, the phase-1 fallback) run on a
   // context of their own: the batch call may come from the B&B driver's worker thread while the calling thread
   // uses `main` for cut rows and solution queries
   SolveCtx aux;
-  // slab recycling (B&B clones come and go at one size)
-  std::multimap<size_t, void *> free_slabs;
-  size_t cached_bytes = 0;
-  // slabs carved out of one multi-slab allocation (a growing B&B tree asks for one slab per open node:
-  // hipMalloc costs ~60 us a call, a chunk of 32 amortises it).  They are recycled through free_slabs
-  // like any other slab but never hipFree'd one by one.
-  std::unordered_set<void *> arena_slabs;
+  SlabCache slabs;
   // profiling (main context only)
   bool prof = false;
   double prof_update_ms = 0.0;
   long long prof_update_n = 0;
   std::vector<hipEvent_t> ev_pool;
 };
+#define MAIN_LOCK(c) std::lock_guard<std::recursive_mutex> main_lock_((c).main_mu)
 
 static Context *g_ctx = nullptr;
+static std::mutex g_ctx_mu;
+static std::atomic<int> g_last_error{0}; // MVX_ENOMEM ...: read and cleared by mvx_last_error()
 static int g_stall_limit = 0;      // > 0: overrides 64 + (m+n)/8 (tests drive the anti-stalling rules with it)
 static int g_requested_dev = -1;
 
@@ -118,7 +139,10 @@ static void init_solve_ctx(SolveCtx &sc) {
   HIPCHECK(hipEventCreate(&sc.ev_b));
 }
 
+int take_last_error() { return g_last_error.exchange(0); }
+
 static Context &ctx() {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
   if (g_ctx) return *g_ctx;
   int n = device_count();
   if (n <= 0) {
@@ -243,92 +267,123 @@ static void bind_slab(mvx_prob *P, void *slab, int m_cap, int ld) {
   P->d_nub = (double *)(b + L.o_nub);
 }
 
+static const size_t SLAB_CACHE_LIMIT = (size_t)8 << 30; // idle bytes kept for reuse
+
+// caller holds the cache lock.  Give idle memory back to the driver: every idle slab that is not part of an arena, and
+// every arena whose slabs are all idle; stops once the idle bytes are at or below `keep`.
+static void slab_trim(SlabCache &sc, size_t keep) {
+  if (sc.idle_bytes <= keep) return;
+  (void)hipDeviceSynchronize(); // queued work may still read a slab that was recycled a moment ago
+  for (auto it = sc.free_slabs.begin(); it != sc.free_slabs.end() && sc.idle_bytes > keep;) {
+    if (sc.arena_of.count(it->second)) {
+      ++it;
+      continue;
+    }
+    (void)hipFree(it->second);
+    sc.idle_bytes -= it->first;
+    it = sc.free_slabs.erase(it);
+  }
+  for (size_t a = 0; a < sc.arenas.size() && sc.idle_bytes > keep; a++) {
+    Arena &ar = sc.arenas[a];
+    if (!ar.base || ar.idle != ar.count) continue;
+    auto range = sc.free_slabs.equal_range(ar.slab_bytes);
+    for (auto it = range.first; it != range.second;) {
+      auto f = sc.arena_of.find(it->second);
+      if (f != sc.arena_of.end() && f->second == (int)a) {
+        sc.arena_of.erase(f);
+        it = sc.free_slabs.erase(it);
+      } else
+        ++it;
+    }
+    (void)hipFree(ar.base);
+    sc.idle_bytes -= ar.slab_bytes * (size_t)ar.count;
+    ar.base = nullptr;
+  }
+}
+
+// nullptr when the device is out of memory even after the idle slabs have been given back (mvx_last_error() then
+// reads MVX_ENOMEM); never aborts
 static void *slab_alloc(Context &c, size_t bytes) {
-  auto it = c.free_slabs.find(bytes);
-  if (it != c.free_slabs.end()) {
+  SlabCache &sc = c.slabs;
+  std::lock_guard<std::mutex> lk(sc.mu);
+  auto it = sc.free_slabs.find(bytes);
+  if (it != sc.free_slabs.end()) {
     void *p = it->second;
-    c.free_slabs.erase(it);
-    if (!c.arena_slabs.count(p)) c.cached_bytes -= bytes;
+    sc.free_slabs.erase(it);
+    sc.idle_bytes -= bytes;
+    auto f = sc.arena_of.find(p);
+    if (f != sc.arena_of.end()) sc.arenas[(size_t)f->second].idle--;
     return p;
   }
   void *p = nullptr;
   if (bytes <= ((size_t)64 << 20)) {
     const size_t count = std::min<size_t>(32, std::max<size_t>(2, ((size_t)256 << 20) / bytes));
     if (hipMalloc(&p, bytes * count) == hipSuccess) {
+      Arena ar;
+      ar.base = p;
+      ar.slab_bytes = bytes;
+      ar.count = (int)count;
+      ar.idle = (int)count - 1;
+      const int a = (int)sc.arenas.size();
+      sc.arenas.push_back(ar);
       for (size_t k = 0; k < count; k++) {
         void *q = (unsigned char *)p + k * bytes;
-        c.arena_slabs.insert(q);
-        if (k) c.free_slabs.emplace(bytes, q);
+        sc.arena_of.emplace(q, a);
+        if (k) sc.free_slabs.emplace(bytes, q);
       }
+      sc.idle_bytes += bytes * (count - 1);
       return p;
     }
     (void)hipGetLastError();
     p = nullptr;
   }
-  hipError_t e = hipMalloc(&p, bytes);
-  if (e != hipSuccess) {
-    // drop the cache (what can be freed of it) and retry once
-    sync_stream();
-    for (auto it2 = c.free_slabs.begin(); it2 != c.free_slabs.end();) {
-      if (c.arena_slabs.count(it2->second)) {
-        ++it2;
-        continue;
-      }
-      (void)hipFree(it2->second);
-      c.cached_bytes -= it2->first;
-      it2 = c.free_slabs.erase(it2);
-    }
-    HIPCHECK(hipMalloc(&p, bytes));
-  }
-  return p;
+  if (hipMalloc(&p, bytes) == hipSuccess) return p;
+  (void)hipGetLastError();
+  slab_trim(sc, 0); // give everything idle back and retry once
+  if (hipMalloc(&p, bytes) == hipSuccess) return p;
+  (void)hipGetLastError();
+  g_last_error.store(MVX_ENOMEM);
+  return nullptr;
 }
 
-// back to the cache; `may_free`: release it to the driver instead when the cache is full
-static void slab_recycle(Context &c, SolveCtx &sc, void *slab, size_t bytes) {
-  if (c.arena_slabs.count(slab)) {
-    c.free_slabs.emplace(bytes, slab);
-    return;
-  }
-  const size_t cache_limit = (size_t)8 << 30;
-  if (c.cached_bytes + bytes <= cache_limit) {
-    c.free_slabs.emplace(bytes, slab);
-    c.cached_bytes += bytes;
-  } else {
-    HIPCHECK(hipStreamSynchronize(sc.stream));
-    HIPCHECK(hipFree(slab));
-  }
+// back to the cache (the streams are in order: work already queued on the slab finishes before any reuse)
+static void slab_recycle(Context &c, void *slab, size_t bytes) {
+  SlabCache &sc = c.slabs;
+  std::lock_guard<std::mutex> lk(sc.mu);
+  auto f = sc.arena_of.find(slab);
+  if (f != sc.arena_of.end()) sc.arenas[(size_t)f->second].idle++;
+  sc.free_slabs.emplace(bytes, slab);
+  sc.idle_bytes += bytes;
+  if (sc.idle_bytes > SLAB_CACHE_LIMIT) slab_trim(sc, SLAB_CACHE_LIMIT / 2);
 }
 
 void release_device(mvx_prob *P) {
   if (!P->slab) return;
   Context &c = ctx();
-  SolveCtx &sc = c.main;
-  (void)sc;
-  // the stream is in-order: work already queued on the slab finishes before any reuse
-  slab_recycle(c, sc, P->slab, P->slab_bytes);
+  slab_recycle(c, P->slab, P->slab_bytes);
   P->slab = nullptr;
   P->slab_bytes = 0;
   P->d_T = nullptr;
   P->valid = false;
 }
 
-static void alloc_device(mvx_prob *P, int m_cap, int ld) {
+static bool alloc_device(mvx_prob *P, int m_cap, int ld) {
   Context &c = ctx();
-  SolveCtx &sc = c.main;
-  (void)sc;
   SlabLayout L = slab_layout(m_cap, ld);
   void *slab = slab_alloc(c, L.total);
+  if (!slab) return false;
   bind_slab(P, slab, m_cap, ld);
+  return true;
 }
 
 static int ld_for(int n) { return (int)align_up((size_t)n + 1, LD_ALIGN); }
 
-// grow row capacity, preserving contents
-static void grow_rows(mvx_prob *P, int m_new) {
-  if (m_new + ROW_SPARE <= P->m_cap) return;
+// grow row capacity, preserving contents; false (handle left as it was) when the device is out of memory
+static bool grow_rows(mvx_prob *P, int m_new) {
+  if (m_new + ROW_SPARE <= P->m_cap) return true;
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   const int cap = m_new + ROW_SLACK;
   void *o_slab = P->slab;
   const size_t o_bytes = P->slab_bytes;
@@ -337,6 +392,7 @@ static void grow_rows(mvx_prob *P, int m_new) {
   int *obvar = P->d_bvar, *onvar = P->d_nvar, *onflag = P->d_nflag;
   SlabLayout Ln = slab_layout(cap, ld);
   void *slab = slab_alloc(c, Ln.total);
+  if (!slab) return false;
   bind_slab(P, slab, cap, ld);
   HIPCHECK(hipMemcpyAsync(P->d_T, oT, (size_t)o_rows * ld * 8, hipMemcpyDeviceToDevice, sc.stream));
   HIPCHECK(hipMemcpyAsync(P->d_bvar, obvar, (size_t)o_rows * 4, hipMemcpyDeviceToDevice, sc.stream));
@@ -347,7 +403,8 @@ static void grow_rows(mvx_prob *P, int m_new) {
   HIPCHECK(hipMemcpyAsync(P->d_nlb, onlb, (size_t)ld * 8, hipMemcpyDeviceToDevice, sc.stream));
   HIPCHECK(hipMemcpyAsync(P->d_nub, onub, (size_t)ld * 8, hipMemcpyDeviceToDevice, sc.stream));
   // recycle the old slab (in-order stream: the copies above complete before any reuse)
-  slab_recycle(c, sc, o_slab, o_bytes);
+  slab_recycle(c, o_slab, o_bytes);
+  return true;
 }
 
 // --------------------------------------------------------------------------- helpers
@@ -436,8 +493,8 @@ void refresh_solution(const mvx_prob *Pc) {
   mvx_prob *P = const_cast<mvx_prob *>(Pc);
   if (!P->valid || P->sol_fresh) return;
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   ensure_scratch(sc, P->m_cap, P->ld);
   fill_ctl(sc, P, sc.h_ctl);
   upload_ctl(sc);
@@ -446,14 +503,18 @@ void refresh_solution(const mvx_prob *Pc) {
 }
 
 // ---------------------------------------------------------------------- tableau build
-static void build_slack_tableau(mvx_prob *P) {
+// false: the device is out of memory (mvx_last_error() reads MVX_ENOMEM); the handle stays without a tableau
+static bool build_slack_tableau(mvx_prob *P) {
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   const int m = P->m, n = P->n;
   const int ld = ld_for(n);
   if (P->slab && (P->ld != ld || P->m_cap < m + ROW_SPARE)) release_device(P);
-  if (!P->slab) alloc_device(P, m + ROW_SLACK, ld);
+  if (!P->slab && !alloc_device(P, m + ROW_SLACK, ld)) {
+    P->status = MVX_UNDEF;
+    return false;
+  }
   ensure_scratch(sc, P->m_cap, P->ld);
   P->bvar.assign((size_t)m + 1, 0);
   P->nvar.assign((size_t)n + 1, 0);
@@ -521,6 +582,7 @@ static void build_slack_tableau(mvx_prob *P) {
   P->valid = true;
   P->sol_fresh = false;
   P->status = MVX_UNDEF;
+  return true;
 }
 
 // ------------------------------------------------------------------------------ simplex
@@ -779,7 +841,10 @@ static bool job_prepare(SolveJob &J, mvx_prob *P, const mvx_smcp *parm) {
     J.rc = 0;
     return false;
   }
-  if (!P->valid) build_slack_tableau(P);
+  if (!P->valid && !build_slack_tableau(P)) {
+    J.rc = MVX_EFAIL;
+    return false;
+  }
   remember_tolerances(P, J.parm);
   return true;
 }
@@ -793,6 +858,8 @@ static int engine_simplex_on(mvx_prob *P, const mvx_smcp *parm, bool aux) {
     init_solve_ctx(c.aux);
     c.aux_ready = true;
   }
+  std::unique_lock<std::recursive_mutex> main_lock(c.main_mu, std::defer_lock);
+  if (!aux) main_lock.lock();
   J.sc = aux ? &c.aux : &c.main;
   job_begin(c, J);
   for (;;) {
@@ -957,7 +1024,10 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
       if (rcs) rcs[i] = 0;
       continue;
     }
-    if (!P->valid) build_slack_tableau(P);
+    if (!P->valid && !build_slack_tableau(P)) {
+      if (rcs) rcs[i] = MVX_EFAIL;
+      continue;
+    }
     remember_tolerances(P, parm);
     pending.push_back(i);
     m_cap = std::max(m_cap, P->m_cap);
@@ -1057,8 +1127,8 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
 void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old_ub, double lb, double ub) {
   if (!P->valid) return;
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   const int pos = P->pos[k];
   if (pos > 0) {
     launch_set_basic_bounds(P->d_blb, P->d_bub, pos, lb, ub, sc.stream);
@@ -1086,9 +1156,13 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
 void engine_add_rows(mvx_prob *P, int first, int nrs) {
   if (!P->valid) return;
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
-  grow_rows(P, P->m);
+  if (!grow_rows(P, P->m)) { // out of memory: the tableau is given up, the next solve restarts from the slack basis
+    release_device(P);
+    engine_invalidate(P);
+    return;
+  }
   launch_add_rows(P->d_T, P->ld, P->n, P->d_bvar, P->d_blb, P->d_bub, P->d_nvar, first, nrs, P->m, sc.stream);
   // host mirrors
   for (int i = 1; i < first; i++)
@@ -1105,8 +1179,8 @@ void engine_add_rows(mvx_prob *P, int first, int nrs) {
 // run k_rowcomb with host-provided weights / base, writing row `dst_row` of the tableau
 static void rowcomb_into_row(mvx_prob *P, const std::vector<double> &w, const std::vector<double> &base, int dst_row) {
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   ensure_scratch(sc, P->m_cap, P->ld);
   HIPCHECK(hipStreamSynchronize(sc.stream)); // h_ctl / pageable sources below must not be in flight
   fill_ctl(sc, P, sc.h_ctl);
@@ -1181,9 +1255,15 @@ void engine_copy(mvx_prob *dst, const mvx_prob *src) {
     return;
   }
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   void *slab = slab_alloc(c, src->slab_bytes);
+  if (!slab) { // out of memory: the clone keeps the model only (mvx_last_error() reads MVX_ENOMEM)
+    dst->valid = false;
+    dst->sol_fresh = false;
+    dst->status = MVX_UNDEF;
+    return;
+  }
   bind_slab(dst, slab, src->m_cap, src->ld);
   // only the live rows of T need to travel; the small arrays follow T in one contiguous tail.  When the
   // spare rows in between are few (B&B clones of a small tableau) one call over the whole slab is cheaper
@@ -1203,8 +1283,8 @@ void engine_copy(mvx_prob *dst, const mvx_prob *src) {
 int engine_get_tableau(const mvx_prob *P, double *out) {
   if (!P->valid) return -1;
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   HIPCHECK(hipMemcpy2DAsync(out, (size_t)(P->n + 1) * 8, P->d_T, (size_t)P->ld * 8, (size_t)(P->n + 1) * 8, (size_t)P->m + 1,
                             hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
@@ -1214,8 +1294,8 @@ int engine_get_tableau(const mvx_prob *P, double *out) {
 int engine_get_row(const mvx_prob *P, int row, double *out) {
   if (!P->valid) return -1;
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
-  (void)sc;
   HIPCHECK(hipMemcpyAsync(out, P->d_T + (size_t)row * P->ld, (size_t)(P->n + 1) * 8, hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
   return 0;
@@ -1256,6 +1336,7 @@ long long engine_pack_size(const mvx_prob *P, int m_base) {
 int engine_pack(const mvx_prob *P, int m_base, void *dev_buf) {
   if (m_base < 0 || m_base > P->m) return -1;
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
   const int m = P->m, n = P->n;
   const size_t hb = pack_host_bytes(m, n, m_base);
@@ -1300,6 +1381,7 @@ int engine_pack(const mvx_prob *P, int m_base, void *dev_buf) {
 // bounds, basis and tableau come from the image
 int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   Context &c = ctx();
+  MAIN_LOCK(c);
   SolveCtx &sc = c.main;
   const unsigned char *d = (const unsigned char *)dev_buf;
   PackHdr h;
@@ -1378,8 +1460,7 @@ void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }
 void profile_enable(int on) { ctx().prof = on != 0; }
 void profile_reset() {
   Context &c = ctx();
-  SolveCtx &sc = c.main;
-  (void)sc;
+  MAIN_LOCK(c);
   c.prof_update_ms = 0.0;
   c.prof_update_n = 0;
 }

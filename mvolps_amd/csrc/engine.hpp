@@ -7,6 +7,7 @@ namespace mvx {
 int device_count();
 int set_device(int dev);
 void sync_stream();
+int take_last_error(); // MVX_ENOMEM ... since the last call; clears it
 
 // solve (glp_simplex)
 int engine_simplex(mvx_prob *P, const mvx_smcp *parm);

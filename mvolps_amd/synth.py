@@ -44,3 +44,15 @@ def dense_ilp(m, n, seed=12345, U=3, cap=0.4):
     c = 1.0 + np.floor(rng.uniform(n) * 20.0)
     b = np.floor(cap * A.sum(axis=1))
     return A, b, c, float(U)
+
+
+def load_ilp(api, A, b, c, U):
+    """The ILP of dense_ilp as a problem handle of `api`: max c'x, Ax <= b, 0 <= x <= U, every column integer
+    (GLP_IV) with a finite upper bound (GLP_DB) -- SURVEY.md section 8(d)."""
+    from .capi import DB, IV, LO, MAX, UP
+
+    m, n = A.shape
+    P = api.create()
+    colb = [(DB, 0.0, U) if np.isfinite(U) else (LO, 0.0, 0.0)] * n
+    P.load_general(A, [(UP, 0.0, float(bi)) for bi in b], colb, c, kinds=[IV] * n, direction=MAX)
+    return P

@@ -933,13 +933,20 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
   return ret;
 }
 
+static double g_tol_bnd = 1e-9, g_tol_dj = 1e-9, g_tol_piv = 1e-9; /* behind parm == NULL; see mvx_set_default_tolerances */
+void orc_set_default_tolerances(double tol_bnd, double tol_dj, double tol_piv) {
+  g_tol_bnd = tol_bnd;
+  g_tol_dj = tol_dj;
+  g_tol_piv = tol_piv;
+}
+
 void orc_init_smcp(orc_smcp *parm) {
   parm->msg_lev = 0;
   parm->meth = 1;
   parm->it_lim = -1;
-  parm->tol_bnd = 1e-9;
-  parm->tol_dj = 1e-9;
-  parm->tol_piv = 1e-9;
+  parm->tol_bnd = g_tol_bnd;
+  parm->tol_dj = g_tol_dj;
+  parm->tol_piv = g_tol_piv;
 }
 
 int orc_simplex(orc_prob *P, const orc_smcp *parm) {

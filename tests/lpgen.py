@@ -43,13 +43,9 @@ def bounds_arrays(bnds):
 
 
 def load_ilp(api, A, b, c, U):
-    from mvolps_amd.capi import IV
+    from mvolps_amd import synth
 
-    m, n = A.shape
-    P = api.create()
-    colb = [(DB, 0.0, U) if np.isfinite(U) else (LO, 0.0, 0.0)] * n
-    P.load_general(A, [(UP, 0.0, float(bi)) for bi in b], colb, c, kinds=[IV] * n, direction=MAX)
-    return P
+    return synth.load_ilp(api, A, b, c, U)
 
 
 def degenerate_lp(m, n, seed, frac0=0.9):

@@ -111,7 +111,7 @@ def test_deep_cut_rows_cross_the_spare_rows(gpu, orc):
     300 best-bound nodes only reach depth 33; the repaired mode crosses the boundary at size in the next test.)"""
     from oracle import oracle
 
-    from . import treedigest
+    from mvolps_amd import treedigest
 
     A, b, c, U = synth.dense_ilp(128, 256, 7, 3)
     kw = dict(quirks=1, cut_strat=1, node_strat=1, max_nodes=2500)
