@@ -64,6 +64,7 @@ static void reset_model(mvx_prob *P) {
   P->pert_cnt = 0;
   P->last_ms = 0.0;
   P->bvar.clear(); P->nvar.clear(); P->nflag.clear(); P->pos.clear();
+  P->pending.clear();
   P->sol_fresh = false;
   P->beta.clear(); P->dj.clear();
 }
@@ -99,6 +100,7 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   dst->ctype = src->ctype; dst->clb = src->clb; dst->cub = src->cub;
   dst->status = src->status; dst->it_cnt = src->it_cnt; dst->bland_cnt = src->bland_cnt; dst->pert_cnt = src->pert_cnt; dst->last_ms = 0.0;
   dst->hint_dual = src->hint_dual;
+  dst->pending = src->pending;
   std::memcpy(dst->last_tol, src->last_tol, sizeof(dst->last_tol));
   dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
   dst->sol_fresh = src->sol_fresh; dst->beta = src->beta; dst->dj = src->dj;

@@ -41,6 +41,7 @@ void launch_p1_head(Ctl *, hipStream_t);
 void launch_p1_select(Ctl *, hipStream_t);
 void launch_p1_fix(Ctl *, int n, hipStream_t);
 void launch_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count, hipStream_t);
+void launch_copy_many(const CopyBatch &b, hipStream_t);
 void launch_rowcomb(Ctl *, int m, int n, int respect_done, hipStream_t);
 void launch_shift_nonbasic(double *T, int ld, int m, int jj, double delta, hipStream_t);
 void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub, hipStream_t);
@@ -105,6 +106,10 @@ struct Context {
   // uses `main` for cut rows and solution queries
   SolveCtx aux;
   SlabCache slabs;
+  // clones recorded by engine_copy and not yet launched (main_mu held): a round of B&B branchings makes one clone per
+  // branching with only host-side work in between, so they leave as ONE k_copy_many launch when the next entry point
+  // that touches device data arrives (flush_copies)
+  std::vector<CopyJob> copies;
   // profiling (main context only)
   bool prof = false;
   double prof_update_ms = 0.0;
@@ -160,10 +165,27 @@ static Context &ctx() {
 }
 
 static void sync_batch_stream();
+static void flush_copies(Context &c);
 void sync_stream() {
   if (!g_ctx) return;
+  {
+    MAIN_LOCK(*g_ctx);
+    flush_copies(*g_ctx);
+  }
   HIPCHECK(hipStreamSynchronize(g_ctx->main.stream));
   sync_batch_stream();
+}
+
+// caller holds main_mu.  Launch the recorded clones on the main stream, COPY_BATCH ranges per launch.
+static void flush_copies(Context &c) {
+  if (c.copies.empty()) return;
+  for (size_t k0 = 0; k0 < c.copies.size(); k0 += COPY_BATCH) {
+    CopyBatch b;
+    b.count = (int)std::min<size_t>(COPY_BATCH, c.copies.size() - k0);
+    for (int k = 0; k < b.count; k++) b.jobs[k] = c.copies[k0 + (size_t)k];
+    launch_copy_many(b, c.main.stream);
+  }
+  c.copies.clear();
 }
 
 static size_t stage_size(int m_cap, int ld) {
@@ -360,6 +382,17 @@ static void slab_recycle(Context &c, void *slab, size_t bytes) {
 void release_device(mvx_prob *P) {
   if (!P->slab) return;
   Context &c = ctx();
+  {
+    MAIN_LOCK(c);
+    // a recorded clone still reads from / writes to this slab: launch it before the slab can be handed out again
+    const unsigned char *lo = (const unsigned char *)P->slab, *hi = lo + P->slab_bytes;
+    for (const CopyJob &j : c.copies)
+      if (((const unsigned char *)j.src >= lo && (const unsigned char *)j.src < hi) ||
+          ((const unsigned char *)j.dst >= lo && (const unsigned char *)j.dst < hi)) {
+        flush_copies(c);
+        break;
+      }
+  }
   slab_recycle(c, P->slab, P->slab_bytes);
   P->slab = nullptr;
   P->slab_bytes = 0;
@@ -383,6 +416,7 @@ static bool grow_rows(mvx_prob *P, int m_new) {
   if (m_new + ROW_SPARE <= P->m_cap) return true;
   Context &c = ctx();
   MAIN_LOCK(c);
+  flush_copies(c);
   SolveCtx &sc = c.main;
   const int cap = m_new + ROW_SLACK;
   void *o_slab = P->slab;
@@ -465,6 +499,23 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->fstate = F_OFF;
 }
 
+// the handle's pending bound edits ride in the control block of the solve that is about to start
+static void take_edits(mvx_prob *P, Ctl *h) {
+  h->n_edits = (int)P->pending.size();
+  for (int k = 0; k < h->n_edits; k++) {
+    h->edit_row[k] = P->pending[(size_t)k].row;
+    h->edit_lb[k] = P->pending[(size_t)k].lb;
+    h->edit_ub[k] = P->pending[(size_t)k].ub;
+  }
+  P->pending.clear();
+}
+
+// ... or go to the device now (more than MAX_EDITS of them, or something other than a solve needs the bounds there)
+static void flush_edits(SolveCtx &sc, mvx_prob *P) {
+  for (const auto &e : P->pending) launch_set_basic_bounds(P->d_blb, P->d_bub, e.row, e.lb, e.ub, sc.stream);
+  P->pending.clear();
+}
+
 static void upload_ctl(SolveCtx &sc) {
   HIPCHECK(hipMemcpyAsync(sc.d_ctl, sc.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, sc.stream));
 }
@@ -494,6 +545,7 @@ void refresh_solution(const mvx_prob *Pc) {
   if (!P->valid || P->sol_fresh) return;
   Context &c = ctx();
   MAIN_LOCK(c);
+  flush_copies(c);
   SolveCtx &sc = c.main;
   ensure_scratch(sc, P->m_cap, P->ld);
   fill_ctl(sc, P, sc.h_ctl);
@@ -579,6 +631,7 @@ static bool build_slack_tableau(mvx_prob *P) {
   HIPCHECK(hipMemcpyAsync(P->d_nub, nub.data(), (size_t)ld * 8, hipMemcpyHostToDevice, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
   rebuild_pos(P);
+  P->pending.clear(); // the bounds just uploaded are the model's
   P->valid = true;
   P->sol_fresh = false;
   P->status = MVX_UNDEF;
@@ -633,6 +686,7 @@ static void job_begin(Context &c, SolveJob &J) {
   h->tol_dj = J.parm.tol_dj;
   h->tol_piv = J.parm.tol_piv;
   h->budget = pivot_budget(P, J.parm);
+  take_edits(P, h);
   upload_ctl(sc);
   HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
@@ -858,8 +912,9 @@ static int engine_simplex_on(mvx_prob *P, const mvx_smcp *parm, bool aux) {
     init_solve_ctx(c.aux);
     c.aux_ready = true;
   }
-  std::unique_lock<std::recursive_mutex> main_lock(c.main_mu, std::defer_lock);
-  if (!aux) main_lock.lock();
+  std::unique_lock<std::recursive_mutex> main_lock(c.main_mu);
+  flush_copies(c);
+  if (aux) main_lock.unlock();
   J.sc = aux ? &c.aux : &c.main;
   job_begin(c, J);
   for (;;) {
@@ -952,6 +1007,7 @@ static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &pa
   h->phase = PH_START; h->done = D_RUN; h->budget = pivot_budget(P, parm);
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->fstate = F_OFF;
+  take_edits(P, h);
 }
 
 // upload the control blocks of the slots filled since the last flush (host side: bc.h_ctl[k])
@@ -1034,6 +1090,10 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     ld = std::max(ld, P->ld);
     m_max = std::max(m_max, P->m);
     n_max = std::max(n_max, P->n);
+  }
+  {
+    MAIN_LOCK(c);
+    flush_copies(c); // clones recorded since the last device call: one launch for all of them
   }
   if (pending.size() == 1) { // nothing to share a launch with
     const int i = pending[0];
@@ -1131,7 +1191,18 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
   SolveCtx &sc = c.main;
   const int pos = P->pos[k];
   if (pos > 0) {
-    launch_set_basic_bounds(P->d_blb, P->d_bub, pos, lb, ub, sc.stream);
+    // no launch: the edit waits on the handle and rides in the control block of the next solve (k_select applies it)
+    bool merged = false;
+    for (auto &e : P->pending)
+      if (e.row == pos) {
+        e.lb = lb;
+        e.ub = ub;
+        merged = true;
+      }
+    if (!merged) {
+      if ((int)P->pending.size() == MAX_EDITS) flush_edits(sc, P);
+      P->pending.push_back({pos, lb, ub});
+    }
     P->hint_dual = true; // a basic variable's bound moved: the warm start is a dual one (bs.cpp:274,282)
   } else {
     const int jj = -pos;
@@ -1145,6 +1216,7 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
       default: flag = MVX_NS; break;
     }
     P->nflag[jj] = flag;
+    flush_copies(c);
     launch_set_nonbasic(P->d_nlb, P->d_nub, P->d_nflag, jj, lb, ub, flag, sc.stream);
     const double xn = nb_value(flag, lb, ub);
     if (xn != xo) launch_shift_nonbasic(P->d_T, P->ld, P->m, jj, xn - xo, sc.stream);
@@ -1158,6 +1230,7 @@ void engine_add_rows(mvx_prob *P, int first, int nrs) {
   Context &c = ctx();
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
+  flush_copies(c);
   if (!grow_rows(P, P->m)) { // out of memory: the tableau is given up, the next solve restarts from the slack basis
     release_device(P);
     engine_invalidate(P);
@@ -1181,6 +1254,7 @@ static void rowcomb_into_row(mvx_prob *P, const std::vector<double> &w, const st
   Context &c = ctx();
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
+  flush_copies(c);
   ensure_scratch(sc, P->m_cap, P->ld);
   HIPCHECK(hipStreamSynchronize(sc.stream)); // h_ctl / pageable sources below must not be in flight
   fill_ctl(sc, P, sc.h_ctl);
@@ -1240,6 +1314,7 @@ void engine_recompute_cost_row(mvx_prob *P) {
 }
 
 void engine_invalidate(mvx_prob *P) {
+  P->pending.clear();
   P->valid = false;
   P->sol_fresh = false;
   P->status = MVX_UNDEF;
@@ -1266,11 +1341,28 @@ void engine_copy(mvx_prob *dst, const mvx_prob *src) {
   }
   bind_slab(dst, slab, src->m_cap, src->ld);
   // only the live rows of T need to travel; the small arrays follow T in one contiguous tail.  When the
-  // spare rows in between are few (B&B clones of a small tableau) one call over the whole slab is cheaper
-  // than two: the host side of a copy call costs more than the extra bytes
+  // spare rows in between are few (B&B clones of a small tableau) one range over the whole slab is cheaper
+  // than two
   SlabLayout L = slab_layout(src->m_cap, src->ld);
   const size_t live = (size_t)(src->m + 1) * src->ld * 8;
-  if (L.o_bvar - live <= (size_t)1 << 20) {
+  const bool whole = L.o_bvar - live <= (size_t)1 << 20;
+  if (L.total <= ((size_t)64 << 20)) {
+    // small tableau: record the clone; it leaves with the others of this round in one k_copy_many launch.  A source
+    // that is itself waiting to be written by a recorded clone goes first.
+    const unsigned char *lo = (const unsigned char *)src->slab, *hi = lo + src->slab_bytes;
+    for (const CopyJob &j : c.copies)
+      if ((const unsigned char *)j.dst >= lo && (const unsigned char *)j.dst < hi) {
+        flush_copies(c);
+        break;
+      }
+    if (whole) {
+      c.copies.push_back({src->slab, slab, L.total});
+    } else {
+      c.copies.push_back({src->d_T, dst->d_T, live});
+      c.copies.push_back({(const unsigned char *)src->slab + L.o_bvar, (unsigned char *)slab + L.o_bvar, L.total - L.o_bvar});
+    }
+    if (c.copies.size() >= 4 * COPY_BATCH) flush_copies(c);
+  } else if (whole) {
     HIPCHECK(hipMemcpyAsync(slab, src->slab, L.total, hipMemcpyDeviceToDevice, sc.stream));
   } else {
     HIPCHECK(hipMemcpyAsync(dst->d_T, src->d_T, live, hipMemcpyDeviceToDevice, sc.stream));
@@ -1285,6 +1377,7 @@ int engine_get_tableau(const mvx_prob *P, double *out) {
   Context &c = ctx();
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
+  flush_copies(c);
   HIPCHECK(hipMemcpy2DAsync(out, (size_t)(P->n + 1) * 8, P->d_T, (size_t)P->ld * 8, (size_t)(P->n + 1) * 8, (size_t)P->m + 1,
                             hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
@@ -1296,6 +1389,7 @@ int engine_get_row(const mvx_prob *P, int row, double *out) {
   Context &c = ctx();
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
+  flush_copies(c);
   HIPCHECK(hipMemcpyAsync(out, P->d_T + (size_t)row * P->ld, (size_t)(P->n + 1) * 8, hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
   return 0;
@@ -1338,6 +1432,8 @@ int engine_pack(const mvx_prob *P, int m_base, void *dev_buf) {
   Context &c = ctx();
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
+  flush_copies(c);
+  if (P->valid) flush_edits(sc, const_cast<mvx_prob *>(P)); // the image carries the device-side bounds
   const int m = P->m, n = P->n;
   const size_t hb = pack_host_bytes(m, n, m_base);
   std::vector<unsigned char> host(hb, 0);
@@ -1382,6 +1478,7 @@ int engine_pack(const mvx_prob *P, int m_base, void *dev_buf) {
 int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   Context &c = ctx();
   MAIN_LOCK(c);
+  flush_copies(c);
   SolveCtx &sc = c.main;
   const unsigned char *d = (const unsigned char *)dev_buf;
   PackHdr h;
@@ -1429,6 +1526,7 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   std::memcpy(dst->last_tol, h.last_tol, sizeof(dst->last_tol));
   dst->sol_fresh = false;
   release_device(dst);
+  dst->pending.clear();
   dst->valid = false;
   if (h.valid) {
     SlabLayout L = slab_layout((int)h.m_cap, (int)h.ld);

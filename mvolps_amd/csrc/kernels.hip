@@ -425,6 +425,16 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
   c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
   const KC k = load_kc(c); // every pointer / constant the step needs, fetched in one burst
   if (c->done != D_RUN) return;
+  const int ne = c->n_edits;
+  if (ne) { // first step of a solve: the bound edits made since the last one (one lane each)
+    if (TIDX < ne) {
+      const int r = c->edit_row[TIDX];
+      k.blb[r] = c->edit_lb[TIDX];
+      k.bub[r] = c->edit_ub[TIDX];
+    }
+    __syncthreads();
+    if (TIDX == 0) c->n_edits = 0;
+  }
   int phase = c->phase, rounds = c->rounds;
   int p = 0, p_up = 0, q = 0, sdir = 0, kind = 0; // kind 1 primal, 2 dual
   bool fresh_dual = false; // the dual phase starts with this step: devex weights restart from one
@@ -699,12 +709,31 @@ __global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
 }
 
 // ---------------------------------------------------------------------------- k_update
+template <int NT>
+__device__ __forceinline__ double2 ld2(const double2 *p) {
+  if (NT) {
+    double2 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+  }
+  return *p;
+}
+template <int NT>
+__device__ __forceinline__ void st2(double2 *p, double2 v) {
+  if (NT) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+  } else
+    *p = v;
+}
+
 // Gauss-Jordan rank-1 update, streamed: every tableau entry read once and written once.
 //   T[i][j] = fma(-colq[i], srow[j], T[i][j])   (i != p, j != q)
 //   T[i][q] = colq[i] / piv                      (i != p)
 //   T[p][j] = -srow[j], T[p][q] = 1/piv, T[p][0] = xq - srow[0]
 // Block = 256 lanes x 2 columns (16 B per lane, 4 KB per row segment), TR rows deep.
-template <int TR>
+template <int TR, int NT>
 __global__ __launch_bounds__(256) void k_update(Ctl *c) {
   c += blockIdx.z;
   if (c->done != D_RUN || c->step != ST_PIVOT) return;
@@ -738,7 +767,7 @@ __global__ __launch_bounds__(256) void k_update(Ctl *c) {
   double2 v[TR];
   double ci[TR];
 #pragma unroll
-  for (int r = 0; r < TR; r++) v[r] = *reinterpret_cast<const double2 *>(base + (size_t)r * ld);
+  for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
 #pragma unroll
   for (int r = 0; r < TR; r++) ci[r] = colq[r];
 #pragma unroll
@@ -766,7 +795,7 @@ __global__ __launch_bounds__(256) void k_update(Ctl *c) {
     }
   }
 #pragma unroll
-  for (int r = 0; r < TR; r++) *reinterpret_cast<double2 *>(base + (size_t)r * ld) = v[r];
+  for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
 }
 
 // ---------------------------------------------------------------------------- k_rowcomb
@@ -1060,25 +1089,6 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
   }
 }
 
-template <int NT>
-__device__ __forceinline__ double2 ld2(const double2 *p) {
-  if (NT) {
-    double2 v;
-    v.x = __builtin_nontemporal_load(&p->x);
-    v.y = __builtin_nontemporal_load(&p->y);
-    return v;
-  }
-  return *p;
-}
-template <int NT>
-__device__ __forceinline__ void st2(double2 *p, double2 v) {
-  if (NT) {
-    __builtin_nontemporal_store(v.x, &p->x);
-    __builtin_nontemporal_store(v.y, &p->y);
-  } else
-    *p = v;
-}
-
 // Row block rb covers rows 1 + rb*TR .. (rb+1)*TR; row 0 (objective) belongs to k_fa.  The slab
 // always has at least 32 spare rows behind row m (mvx::ROW_SPARE), so the last block streams
 // whole tiles too: spare rows are never read by anything else and are re-zeroed when a cut row
@@ -1254,11 +1264,20 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 // ------------------------------------------------------------------ launch wrappers
 
 // tuning knobs of the streamed update (mvx_set_tuning; defaults are the measured best)
-static int g_tr = 0, g_hot = 1, g_nt = 0; // g_tr 0 = pick from the grid size
+static int g_tr = 0, g_hot = 1, g_nt = -1; // g_tr 0 = pick from the grid size; g_nt -1 = pick from the tableau size
 void set_tuning(int tr, int hot, int nt) {
   g_tr = (tr == 4 || tr == 8 || tr == 16 || tr == 32) ? tr : 0;
   g_hot = hot ? 1 : 0;
-  g_nt = nt ? 1 : 0;
+  g_nt = (nt == 0 || nt == 1) ? nt : -1;
+}
+// Non-temporal loads and stores once the tableau no longer fits the 256 MiB Infinity Cache: every entry is touched
+// once per pivot, so lines kept for reuse only evict each other -- 8192x8192 (537 MB): 5.34 -> 6.13 TB/s
+// (profiles/r02_sweep_nt_8192x8192.jsonl).  Below that size the cache holds most of the tableau from one pivot to
+// the next and the default policy is faster (round 1's sweep at 4096x8192).
+static int pick_nt(int m, int n) {
+  if (g_nt >= 0) return g_nt;
+  const size_t bytes = (size_t)(m + 1) * (size_t)((n + 1 + LD_ALIGN - 1) / LD_ALIGN * LD_ALIGN) * 8;
+  return bytes > NT_THRESHOLD_BYTES ? 1 : 0;
 }
 // row-block depth: 16 rows per block once that still gives every CU several blocks, else 8
 static int pick_tr(int m, int n) {
@@ -1275,9 +1294,10 @@ void launch_fa(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fa, dim3
 void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
   const int pairs = (n + 2) / 2;
   const int tr = pick_tr(m, n);
+  const int nt = pick_nt(m, n);
   dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
 #define FB_CASE(TR_, HOT_, NT_) \
-  if (tr == TR_ && g_hot == HOT_ && g_nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
+  if (tr == TR_ && g_hot == HOT_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
   FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
   FB_CASE(8, 0, 0) FB_CASE(32, 0, 0) FB_CASE(8, 0, 1) FB_CASE(16, 0, 1) FB_CASE(32, 0, 1)
   FB_CASE(4, 1, 0) FB_CASE(4, 0, 0) FB_CASE(4, 1, 1) FB_CASE(4, 0, 1)
@@ -1291,9 +1311,10 @@ void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
   // 16-row tiles once the launch still has >= 2048 workgroups, else 8, else 4 (latency-bound sizes)
   const int tr = ((long)((m + 16) / 16) * tiles * slots >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * slots >= 2048) ? 8 : 4;
   dim3 grid((unsigned)tiles, (m + tr) / tr, slots);
-  if (tr == 16) hipLaunchKernelGGL(k_update<16>, grid, dim3(256), 0, s, d_ctl);
-  else if (tr == 8) hipLaunchKernelGGL(k_update<8>, grid, dim3(256), 0, s, d_ctl);
-  else hipLaunchKernelGGL(k_update<4>, grid, dim3(256), 0, s, d_ctl);
+  if (tr == 16 && pick_nt(m, n)) hipLaunchKernelGGL((k_update<16, 1>), grid, dim3(256), 0, s, d_ctl);
+  else if (tr == 16) hipLaunchKernelGGL((k_update<16, 0>), grid, dim3(256), 0, s, d_ctl);
+  else if (tr == 8) hipLaunchKernelGGL((k_update<8, 0>), grid, dim3(256), 0, s, d_ctl);
+  else hipLaunchKernelGGL((k_update<4, 0>), grid, dim3(256), 0, s, d_ctl);
 }
 void launch_p1_head(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_head, dim3(1), dim3(1024), 0, s, d_ctl); }
 void launch_p1_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_select, dim3(1), dim3(1024), 0, s, d_ctl); }
@@ -1308,6 +1329,37 @@ __global__ __launch_bounds__(64) void k_scatter_ctl(Ctl *dst, const Ctl *src, co
 }
 void launch_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count, hipStream_t s) {
   hipLaunchKernelGGL(k_scatter_ctl, dim3(count), dim3(64), 0, s, dst, src, idx, count);
+}
+// Device-to-device clones of a round of B&B branchings (glp_copy_prob, bs.cpp:269-273) in ONE launch: a 4 MB copy
+// on its own cannot fill the chip (5.9 us each as separate copyBuffer launches), 64 of them together stream at HBM rate.
+__global__ __launch_bounds__(256) void k_copy_many(CopyBatch b) {
+  const CopyJob j = b.jobs[blockIdx.y];
+  const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(j.src);
+  uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(j.dst);
+  const size_t n = j.bytes >> 4;
+  constexpr int U = 8;
+  for (size_t base = (size_t)blockIdx.x * (256 * U); base < n; base += (size_t)gridDim.x * (256 * U)) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t i = base + (size_t)u * 256 + TIDX;
+      if (i < n) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t i = base + (size_t)u * 256 + TIDX;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+void launch_copy_many(const CopyBatch &b, hipStream_t s) {
+  size_t mx = 0;
+  for (int k = 0; k < b.count; k++) mx = b.jobs[k].bytes > mx ? b.jobs[k].bytes : mx;
+  const size_t per_block = (size_t)256 * 8 * 16;
+  unsigned gx = (unsigned)((mx + per_block - 1) / per_block);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_copy_many, dim3(gx, (unsigned)b.count), dim3(256), 0, s, b);
 }
 void launch_p1_fix(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_p1_fix, dim3((n + 1 + 255) / 256), dim3(256), 0, s, d_ctl); }
 void launch_rowcomb(Ctl *d_ctl, int m, int n, int respect_done, hipStream_t s) {

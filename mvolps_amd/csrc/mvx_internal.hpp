@@ -23,6 +23,8 @@ constexpr int LD_ALIGN = 32;      // doubles; 256-byte rows
 constexpr int ROW_SLACK = 64;     // spare tableau rows per handle for cut appends (cut.cpp:23)
 constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this counts as degenerate (oracle: DEGEN_TOL)
 constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
+constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
+constexpr int MAX_EDITS = 4;      // pending bound edits a control block carries (more are flushed by launches)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
 
 // state-machine phases (device-driven; mirrors orc_simplex's round loop)
@@ -87,6 +89,23 @@ struct Ctl {
   double *dw; // [m_cap+1] dual devex reference weights by row (oracle: dual_simplex's w), reset on entering the dual phase
   int stall_new; // fused path: k_fa's verdict on the step it prepared, committed by k_fb (k_fa workgroups read `stall`)
   double ent_lb, ent_ub;
+  // bound edits of basic variables made since the last solve (glp_set_col_bnds on a branching child, bs.cpp:274,282;
+  // glp_set_row_bnds on a fresh cut row, cut.cpp:43): applied by the first k_select of the solve instead of one
+  // launch per edit
+  int n_edits, edit_row[MAX_EDITS];
+  double edit_lb[MAX_EDITS], edit_ub[MAX_EDITS];
+};
+
+// one launch of k_copy_many: up to COPY_BATCH byte ranges (16-byte aligned, sizes multiples of 16)
+constexpr int COPY_BATCH = 32;
+struct CopyJob {
+  const void *src;
+  void *dst;
+  size_t bytes;
+};
+struct CopyBatch {
+  int count;
+  CopyJob jobs[COPY_BATCH];
 };
 
 // shared immutable matrix row (1-based, n+1 doubles)
@@ -115,6 +134,12 @@ struct mvx_prob {
   double last_ms = 0.0;
   double last_tol[3] = {0.0, 0.0, 0.0}; // tolerances of the solve that produced `status`
   bool hint_dual = false; // last edit made a basic variable infeasible: start in the dual simplex
+  // bound edits of basic variables not yet on the device: (row position, lb, ub); the next solve's control block carries them
+  struct Edit {
+    int row;
+    double lb, ub;
+  };
+  std::vector<Edit> pending;
   // host mirrors of the basis (always in sync while valid)
   std::vector<int> bvar, nvar, nflag; // [m+1], [n+1], [n+1]
   std::vector<int> pos;               // pos[k], k=1..m+n: +row or -column

@@ -13,7 +13,7 @@ api = mvolps_amd.api()
 mvolps_amd.require_device()
 A, b, c = synth.dense_lp(m, n, 12345)
 ref = None
-variants = [(0, 1, 0), (4, 1, 0), (8, 1, 0), (16, 1, 0), (0, 1, 0)]
+variants = [(0, 1, 0), (8, 1, 0), (16, 1, 0), (32, 1, 0), (8, 1, 1), (16, 1, 1), (32, 1, 1), (0, 1, 0)]
 for (tr, hot, nt) in variants:
     api.set_tuning(tr, hot, nt)
     P = api.create()
