@@ -142,6 +142,14 @@ int mvx_get_bland_cnt(const mvx_prob *P);
 int mvx_term_out(int flag);      /* glp_term_out 2test.cpp:45,53,62 */
 const char *mvx_version(void);   /* glp_version  util.cpp:278 */
 
+/* generateCut3 (gmi.cpp:11-117) for `count` basic integer columns cols[0..count-1] (1-based) of a solved node in one
+   device pass: tableau rows, the coefficient formula and the back-substitution over the model rows run on the GPU.
+   vals is count x (n+1), row-major: vals[t][1..n] the cut coefficients, vals[t][0] = rhs[t] = its lower bound
+   (the CutContainer of gmi.cpp:91-109); ok[t] = 0 where no cut exists.  repaired = 0: the formula as written, running
+   right-hand side and positional back-substitution included; 1: mvx_generateCutGMI's.  Bit-identical to the
+   one-column host functions of mvx_bnb.h.  Returns 0, -1 on bad arguments, -2 when the device is out of memory */
+int mvx_gmi_cuts(const mvx_prob *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok);
+
 /* ---- engine-state access (parity tests, visualisers) --------------------------- */
 int mvx_get_tableau_ld(const mvx_prob *P);
 int mvx_get_tableau(const mvx_prob *P, double *out); /* (m+1) x (n+1), packed row-major */

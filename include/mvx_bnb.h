@@ -57,6 +57,10 @@ typedef struct mvx_lp_api {
      (bs.cpp:172,210) whatever the direction; with reference_quirks = 0 the driver turns the compares
      round for a minimisation problem */
   int (*get_obj_dir)(const void *P);
+  /* optional (may be NULL): generateCut3 / the repaired formula for `count` basic integer columns of a solved node in
+     one call (mvx_gmi_cuts: tableau rows, coefficient formula and back-substitution on the device); the driver then
+     generates a node's cuts through it instead of one eval_tab_row + m get_mat_row calls per cut */
+  int (*gmi_cuts)(const void *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok);
 } mvx_lp_api;
 
 const mvx_lp_api *mvx_hip_lp_api(void);

@@ -375,22 +375,84 @@ void pack_result(mvx_bnb_result *res, const Recorder &rec, int id, int count, in
   res->hit_limit = hit_limit;
 }
 
+// A node's cuts through the engine's batch entry (mvx_lp_api.gmi_cuts): `cols` are the candidate columns (each one
+// basic and integer, checked by the caller the way gmi.cpp:18-27 / the repaired filter do); returns one container per
+// column, oid -1 where the engine found no cut.
+static std::vector<CutContainer> cuts_via_engine(const mvx_lp_api *api, const void *a, bool repaired, const std::vector<int> &cols,
+                                                 std::vector<double> *eff) {
+  const int n = api->get_num_cols(a), k = (int)cols.size();
+  std::vector<double> vals((size_t)k * (n + 1)), rhs((size_t)k);
+  std::vector<int> ok((size_t)k, 0);
+  std::vector<CutContainer> out((size_t)k);
+  if (api->gmi_cuts(a, repaired ? 1 : 0, cols.data(), k, vals.data(), rhs.data(), ok.data()) != 0) {
+    for (auto &c : out) c.oid = -1;
+    return out;
+  }
+  std::vector<double> x;
+  if (repaired) {
+    x.resize((size_t)n + 1);
+    for (int j = 1; j <= n; j++) x[(size_t)j] = api->get_col_prim(a, j);
+  }
+  for (int t = 0; t < k; t++) {
+    CutContainer &c = out[(size_t)t];
+    if (!ok[(size_t)t]) {
+      c.oid = -1;
+      continue;
+    }
+    const double *v = &vals[(size_t)t * (n + 1)];
+    c.inds.resize((size_t)n + 1);
+    c.vals.assign(v, v + n + 1);
+    for (int j = 0; j <= n; j++) c.inds[(size_t)j] = j;
+    c.lb = rhs[(size_t)t];
+    c.oid = 0;
+    if (repaired) { // efficacy as generateCutGMI computes it
+      double dot = 0.0, nrm = 0.0;
+      for (int j = 1; j <= n; j++) {
+        dot += c.vals[(size_t)j] * x[(size_t)j];
+        nrm += c.vals[(size_t)j] * c.vals[(size_t)j];
+      }
+      if (!(nrm > 0.0)) {
+        c.oid = -1;
+        continue;
+      }
+      if (eff) (*eff)[(size_t)t] = (c.lb - dot) / std::sqrt(nrm);
+    }
+  }
+  return out;
+}
+
+// generateCutGMI's own rejections that need no tableau row (the rest is the engine's ok flag)
+static bool gmi_candidate(const mvx_lp_api *api, const void *a, int j) {
+  if (api->get_col_kind(a, j) == MVX_CV || api->get_col_stat(a, j) != MVX_BS) return false;
+  const double f0 = getFract(api->get_col_prim(a, j));
+  return !(f0 < 1e-6 || f0 > 1.0 - 1e-6);
+}
+
 // Cut step of a branching node (bs.cpp:249-258), shared by both drivers: bug-compatible mode feeds the
 // persistent pool and appends its last cut (cut.cpp:16-21); repaired mode appends this node's own GMI cuts,
 // chosen by cut_select / -cf.
 // Returns the number of rows appended; -1 when the bug-compatible path found its pool empty (nothing generated yet).
 static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &prm, bool quirks, CutPool &pool) {
   if (prm.cut_strat == 0) return 0;
+  const int na = api->get_num_cols(a);
+  const bool dev = api->gmi_cuts != nullptr;
   if (quirks) {
-    const int na = api->get_num_cols(a);
     if (prm.lazy_pool) {
       // only the pool's LAST cut is ever added (cut.cpp:20): generate just that one
       for (int j = na; j >= 1; j--) {
         if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) {
-          pool.replaceLast(generateCut3(api, a, j));
+          if (dev) pool.replaceLast(std::move(cuts_via_engine(api, a, false, {j}, nullptr)[0]));
+          else pool.replaceLast(generateCut3(api, a, j));
           break;
         }
       }
+    } else if (dev) {
+      std::vector<int> cols;
+      for (int j = 1; j <= na; j++)
+        if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) cols.push_back(j); // gmi.cpp:18-27
+      if (!cols.empty())
+        for (auto &c : cuts_via_engine(api, a, false, cols, nullptr))
+          if (c.oid != -1) pool.addToPool(std::move(c));
     } else {
       for (int j = 1; j <= na; j++) {
         CutContainer result = generateCut3(api, a, j);
@@ -399,7 +461,6 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
     }
     return pool.addCutConstraint(a) < 0 ? -1 : 1;
   }
-  const int na = api->get_num_cols(a);
   std::vector<CutContainer> local;
   std::vector<double> eff;
   if (prm.cut_select == 0 && prm.lazy_pool) {
@@ -407,11 +468,32 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
     // generating one cut per basic integer column (each is a tableau row read + an O(m n) back-substitution)
     for (int j = na; j >= 1 && local.empty(); j--) {
       double e = 0.0;
-      CutContainer c = generateCutGMI(api, a, j, &e);
+      CutContainer c;
+      if (dev) {
+        if (!gmi_candidate(api, a, j)) continue;
+        std::vector<double> e1(1, 0.0);
+        c = std::move(cuts_via_engine(api, a, true, {j}, &e1)[0]);
+        e = e1[0];
+      } else {
+        c = generateCutGMI(api, a, j, &e);
+      }
       if (c.oid != -1) {
         local.push_back(std::move(c));
         eff.push_back(e);
       }
+    }
+  } else if (dev) {
+    std::vector<int> cols;
+    for (int j = 1; j <= na; j++)
+      if (gmi_candidate(api, a, j)) cols.push_back(j);
+    if (!cols.empty()) {
+      std::vector<double> e(cols.size(), 0.0);
+      std::vector<CutContainer> all = cuts_via_engine(api, a, true, cols, &e);
+      for (size_t t = 0; t < all.size(); t++)
+        if (all[t].oid != -1) {
+          local.push_back(std::move(all[t]));
+          eff.push_back(e[t]);
+        }
     }
   } else {
     for (int j = 1; j <= na; j++) {
@@ -889,6 +971,9 @@ const mvx_lp_api g_hip_api = {
       return mvx_simplex_batch((mvx_prob **)probs, count, (const mvx_smcp *)parm, rcs);
     },
     [](const void *P) { return mvx_get_obj_dir((const mvx_prob *)P); },
+    [](const void *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
+      return mvx_gmi_cuts((const mvx_prob *)P, repaired, cols, count, vals, rhs, ok);
+    },
 };
 
 } // namespace

@@ -65,6 +65,7 @@ static void reset_model(mvx_prob *P) {
   P->last_ms = 0.0;
   P->bvar.clear(); P->nvar.clear(); P->nflag.clear(); P->pos.clear();
   P->pending.clear();
+  P->dmat.reset();
   P->sol_fresh = false;
   P->beta.clear(); P->dj.clear();
 }
@@ -101,6 +102,7 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   dst->status = src->status; dst->it_cnt = src->it_cnt; dst->bland_cnt = src->bland_cnt; dst->pert_cnt = src->pert_cnt; dst->last_ms = 0.0;
   dst->hint_dual = src->hint_dual;
   dst->pending = src->pending;
+  dst->dmat = src->dmat;
   std::memcpy(dst->last_tol, src->last_tol, sizeof(dst->last_tol));
   dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
   dst->sol_fresh = src->sol_fresh; dst->beta = src->beta; dst->dj = src->dj;
@@ -417,6 +419,10 @@ int mvx_get_basis(const mvx_prob *P, int *head, int *nb, int *flag) {
     flag[j] = P->nflag[j];
   }
   return 0;
+}
+
+int mvx_gmi_cuts(const mvx_prob *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
+  return mvx::engine_gmi_cuts(P, repaired ? 1 : 0, cols, count, vals, rhs, ok);
 }
 
 int mvx_device_count(void) { return mvx::device_count(); }

@@ -17,6 +17,21 @@
 
 #include "engine.hpp"
 
+// Device copy of model rows 1..m0 (see mvx_prob::dmat).  `plain` is indexed by column; `packed` holds each row's
+// non-zeros side by side (what position k of glp_get_mat_row's list means, gmi.cpp:84-87) and is the same buffer
+// when every row is dense.
+struct DevMatrix {
+  int m0 = 0, n = 0, lda = 0;
+  double *plain = nullptr, *packed = nullptr;
+  int *len = nullptr; // nullptr: every row has n non-zeros
+  std::vector<const void *> rows; // identity of the host rows this was built from
+  ~DevMatrix() {
+    if (packed && packed != plain) (void)hipFree(packed);
+    if (plain) (void)hipFree(plain);
+    if (len) (void)hipFree(len);
+  }
+};
+
 namespace mvx {
 
 #define HIPCHECK(expr)                                                                         \
@@ -42,6 +57,7 @@ void launch_p1_select(Ctl *, hipStream_t);
 void launch_p1_fix(Ctl *, int n, hipStream_t);
 void launch_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count, hipStream_t);
 void launch_copy_many(const CopyBatch &b, hipStream_t);
+void launch_gmi(const GmiArgs &a, hipStream_t);
 void launch_rowcomb(Ctl *, int m, int n, int respect_done, hipStream_t);
 void launch_shift_nonbasic(double *T, int ld, int m, int jj, double delta, hipStream_t);
 void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub, hipStream_t);
@@ -110,6 +126,10 @@ struct Context {
   // branching with only host-side work in between, so they leave as ONE k_copy_many launch when the next entry point
   // that touches device data arrives (flush_copies)
   std::vector<CopyJob> copies;
+  // GMI cut generation (engine_gmi_cuts): device buffers for `work`, the cuts, right-hand sides, flags, row positions
+  // and column kinds, and the pinned host side of the transfers
+  void *gmi_dev = nullptr, *gmi_host = nullptr;
+  size_t gmi_bytes = 0;
   // profiling (main context only)
   bool prof = false;
   double prof_update_ms = 0.0;
@@ -1392,6 +1412,158 @@ int engine_get_row(const mvx_prob *P, int row, double *out) {
   flush_copies(c);
   HIPCHECK(hipMemcpyAsync(out, P->d_T + (size_t)row * P->ld, (size_t)(P->n + 1) * 8, hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------ GMI cuts (gmi.cpp:11-117)
+static std::shared_ptr<DevMatrix> build_dev_matrix(Context &c, const mvx_prob *P) {
+  SolveCtx &sc = c.main;
+  auto D = std::make_shared<DevMatrix>();
+  const int m0 = P->m, n = P->n;
+  const int lda = (int)align_up((size_t)n + 1, LD_ALIGN);
+  D->m0 = m0;
+  D->n = n;
+  D->lda = lda;
+  std::vector<double> plain((size_t)(m0 + 1) * lda, 0.0), packed;
+  std::vector<int> len((size_t)m0 + 1, 0);
+  bool dense = true;
+  for (int i = 1; i <= m0; i++) {
+    const double *a = P->A[(size_t)i]->data();
+    D->rows.push_back(P->A[(size_t)i].get());
+    std::memcpy(&plain[(size_t)i * lda + 1], a + 1, (size_t)n * 8);
+    int l = 0;
+    for (int j = 1; j <= n; j++) l += (a[j] != 0.0);
+    len[(size_t)i] = l;
+    dense = dense && l == n;
+  }
+  const size_t bytes = plain.size() * 8;
+  if (hipMalloc((void **)&D->plain, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    g_last_error.store(MVX_ENOMEM);
+    D->plain = nullptr;
+    return nullptr;
+  }
+  HIPCHECK(hipMemcpyAsync(D->plain, plain.data(), bytes, hipMemcpyHostToDevice, sc.stream));
+  if (dense) {
+    D->packed = D->plain;
+  } else {
+    packed.assign(plain.size(), 0.0);
+    for (int i = 1; i <= m0; i++) {
+      const double *a = P->A[(size_t)i]->data();
+      int l = 0;
+      for (int j = 1; j <= n; j++)
+        if (a[j] != 0.0) packed[(size_t)i * lda + (size_t)(++l)] = a[j];
+    }
+    if (hipMalloc((void **)&D->packed, bytes) != hipSuccess || hipMalloc((void **)&D->len, len.size() * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      g_last_error.store(MVX_ENOMEM);
+      return nullptr;
+    }
+    HIPCHECK(hipMemcpyAsync(D->packed, packed.data(), bytes, hipMemcpyHostToDevice, sc.stream));
+    HIPCHECK(hipMemcpyAsync(D->len, len.data(), len.size() * 4, hipMemcpyHostToDevice, sc.stream));
+  }
+  HIPCHECK(hipStreamSynchronize(sc.stream)); // the pageable sources above go out of scope
+  return D;
+}
+
+// the handle's device matrix still describes its first m0 model rows?
+static bool dev_matrix_current(const mvx_prob *P) {
+  const DevMatrix *D = P->dmat.get();
+  if (!D || D->n != P->n || D->m0 > P->m) return false;
+  for (int i = 1; i <= D->m0; i++)
+    if (D->rows[(size_t)i - 1] != P->A[(size_t)i].get()) return false;
+  return true;
+}
+
+// `count` cuts of the solved handle P, one per structural column cols[t] (1-based, basic): vals[t][0..n] with
+// vals[t][0] = rhs[t] = the cut's lower bound (gmi.cpp:91-109), ok[t] = 0 where no valid cut exists.
+// mode 0 = generateCut3 as written (gmi.cpp:11-117), 1 = the repaired formula (mvx_generateCutGMI).
+int engine_gmi_cuts(const mvx_prob *Pc, int mode, const int *cols, int count, double *vals, double *rhs, int *ok) {
+  mvx_prob *P = const_cast<mvx_prob *>(Pc);
+  if (!P->valid || count < 1) return -1;
+  Context &c = ctx();
+  MAIN_LOCK(c);
+  flush_copies(c);
+  SolveCtx &sc = c.main;
+  const int m = P->m, n = P->n;
+  if (!dev_matrix_current(P)) {
+    P->dmat = build_dev_matrix(c, P);
+    if (!P->dmat) return -2;
+  }
+  const DevMatrix &D = *P->dmat;
+  const size_t wld = align_up((size_t)m + n + 1, 32), old = align_up((size_t)n + 1, 32);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  // [pos i32 x count][kind i32 x (n+1)] go up; [rhs][ok][out][work] come back (work: the auxiliaries' part only)
+  const size_t o_pos = carve((size_t)count * 4), o_kind = carve((size_t)(n + 1) * 4), up_bytes = off;
+  const size_t o_rhs = carve((size_t)count * 8), o_ok = carve((size_t)count * 4);
+  const size_t o_out = carve((size_t)count * old * 8), o_work = carve((size_t)count * wld * 8);
+  if (off > c.gmi_bytes) {
+    HIPCHECK(hipStreamSynchronize(sc.stream));
+    if (c.gmi_dev) HIPCHECK(hipFree(c.gmi_dev));
+    if (c.gmi_host) HIPCHECK(hipHostFree(c.gmi_host));
+    c.gmi_dev = c.gmi_host = nullptr;
+    c.gmi_bytes = 0;
+    const size_t want = off + off / 2;
+    if (hipMalloc(&c.gmi_dev, want) != hipSuccess) {
+      (void)hipGetLastError();
+      g_last_error.store(MVX_ENOMEM);
+      return -2;
+    }
+    HIPCHECK(hipHostMalloc(&c.gmi_host, want));
+    c.gmi_bytes = want;
+  }
+  unsigned char *hb = (unsigned char *)c.gmi_host, *db = (unsigned char *)c.gmi_dev;
+  int *h_pos = (int *)(hb + o_pos), *h_kind = (int *)(hb + o_kind);
+  for (int t = 0; t < count; t++) {
+    const int j = cols[t];
+    if (j < 1 || j > n || P->pos[(size_t)m + j] <= 0) return -1; // the column must be basic (gmi.cpp:23)
+    h_pos[t] = P->pos[(size_t)m + j];
+  }
+  h_kind[0] = 0;
+  for (int j = 1; j <= n; j++) h_kind[j] = P->kind[(size_t)j];
+  HIPCHECK(hipMemcpyAsync(db, hb, up_bytes, hipMemcpyHostToDevice, sc.stream));
+  GmiArgs a;
+  a.T = P->d_T; a.nvar = P->d_nvar; a.nflag = P->d_nflag; a.nlb = P->d_nlb; a.nub = P->d_nub;
+  a.kind = (const int *)(db + o_kind); a.pos = (const int *)(db + o_pos);
+  a.work = (double *)(db + o_work); a.rhs = (double *)(db + o_rhs); a.ok = (int *)(db + o_ok);
+  a.A = mode == 0 ? D.packed : D.plain; a.len = mode == 0 ? D.len : nullptr; a.out = (double *)(db + o_out);
+  a.ld = P->ld; a.m = m; a.n = n; a.wld = (int)wld; a.lda = D.lda; a.m0 = D.m0; a.old = (int)old; a.count = count; a.mode = mode;
+  launch_gmi(a, sc.stream);
+  HIPCHECK(hipMemcpyAsync(hb + o_rhs, db + o_rhs, o_work - o_rhs, hipMemcpyDeviceToHost, sc.stream)); // rhs, ok, out
+  if (m > D.m0) // the auxiliaries of the rows appended since: their terms are added below
+    HIPCHECK(hipMemcpy2DAsync(hb + o_work, wld * 8, db + o_work, wld * 8, (size_t)(m + 1) * 8, (size_t)count, hipMemcpyDeviceToHost, sc.stream));
+  HIPCHECK(hipStreamSynchronize(sc.stream));
+  const double *h_rhs = (const double *)(hb + o_rhs), *h_out = (const double *)(hb + o_out), *h_work = (const double *)(hb + o_work);
+  const int *h_ok = (const int *)(hb + o_ok);
+  for (int t = 0; t < count; t++) {
+    double *v = vals + (size_t)t * (n + 1);
+    std::memcpy(v + 1, h_out + (size_t)t * old + 1, (size_t)n * 8);
+    // rows m0+1..m (this node's own cut rows) in order, the way gmi.cpp:81-89 / the repaired loop continue
+    for (int i = D.m0 + 1; i <= m; i++) {
+      const double wi = h_work[(size_t)t * wld + i];
+      const double *ai = P->A[(size_t)i]->data();
+      if (mode == 0) {
+        int l = 0;
+        for (int j = 1; j <= n; j++)
+          if (ai[j] != 0.0) {
+            ++l;
+            v[l] += wi * ai[j]; // position l, not column j (gmi.cpp:87)
+          }
+      } else {
+        if (wi == 0.0) continue;
+        for (int j = 1; j <= n; j++)
+          if (ai[j] != 0.0) v[j] += wi * ai[j];
+      }
+    }
+    v[0] = h_rhs[t];
+    rhs[t] = h_rhs[t];
+    ok[t] = h_ok[t];
+  }
   return 0;
 }
 

@@ -1261,6 +1261,178 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   }
 }
 
+// ======================================================================= GMI cuts on the device
+// generateCut3 (/root/reference/gmi.cpp:11-117) and its repaired variant, for `count` basic integer columns of one
+// solved node at once.  k_gmi_work turns the tableau row of each column into the coefficient vector `work` by
+// variable number (gmi.cpp:41-74): the bug-compatible formula threads a RUNNING right-hand side through the
+// non-basic columns in ascending position order (gmi.cpp:55,73), so one lane walks the row; everything around
+// it (row loads, bound / kind look-ups, the repaired formula's per-column terms) is done by the whole workgroup.
+// k_gmi_backsub is gmi.cpp:81-89: out[col] = work[m+col] + sum over model rows i = 1..m0, in that order, of
+// work[i] * A[i][col] -- multiply and add rounded separately, as the host loop does (-ffp-contract=off).
+// The caller finishes rows m0+1..m (the node's own appended cut rows) on the host, in the same order.
+__device__ __forceinline__ double dev_fract(double x) { // util.cpp:11-23
+  double ip;
+  double f = modf(x, &ip);
+  if (f < 0.0) f += 1;
+  return f;
+}
+__device__ __forceinline__ double api_ub(double ub) { return ub == INFINITY ? 1.79769313486231570815e+308 : ub; }
+__device__ __forceinline__ double api_lb(double lb) { return lb == -INFINITY ? -1.79769313486231570815e+308 : lb; }
+
+constexpr int GMI_CH = 1024; // non-basic positions staged per pass
+
+__global__ __launch_bounds__(256) void k_gmi_work(GmiArgs a) {
+  __shared__ double s_val[GMI_CH], s_aux[GMI_CH];
+  __shared__ int s_var[GMI_CH], s_kind[GMI_CH];
+  __shared__ double s_rhs, s_temp;
+  __shared__ int s_bad;
+  const int c = (int)blockIdx.x;
+  const int m = a.m, n = a.n;
+  const double *row = a.T + (size_t)a.pos[c] * a.ld;
+  double *work = a.work + (size_t)c * a.wld;
+  for (int v = TIDX; v <= m + n; v += 256) work[v] = 0.0;
+  const double beta = row[0];
+  const double f0 = dev_fract(beta);
+  if (TIDX == 0) {
+    s_rhs = a.mode == 0 ? beta : 1.0; // gmi.cpp:37 / the repaired cut's right-hand side starts at 1
+    s_temp = 0.0;                     // `temp` is uninitialised at gmi.cpp:13; 0 here and in the oracle
+    s_bad = 0;
+  }
+  __syncthreads();
+  for (int base = 1; base <= n; base += GMI_CH) {
+    const int cnt = (n - base + 1 < GMI_CH) ? n - base + 1 : GMI_CH;
+    for (int t = TIDX; t < cnt; t += 256) {
+      const int jj = base + t;
+      const double val = row[jj];
+      const int var = a.nvar[jj];
+      // glp_get_col_kind: an integer column with bounds [0,1] reads as GLP_BV; auxiliaries are continuous
+      int kind = MVX_CV;
+      const double lb = a.nlb[jj], ub = a.nub[jj];
+      if (var > m) {
+        kind = a.kind[var - m];
+        if (kind == MVX_IV && lb == 0.0 && ub == 1.0) kind = MVX_BV;
+      }
+      s_val[t] = val;
+      s_var[t] = var;
+      if (a.mode == 0) {
+        s_kind[t] = kind;
+        s_aux[t] = api_ub(ub); // gmi.cpp:47,52
+      } else {
+        // repaired: this column's term of the cut and of its right-hand side
+        const int stat = a.nflag[jj];
+        int code = 0; // 0 skip, 1 at lower, 2 at upper
+        double g = 0.0, term = 0.0;
+        if (val != 0.0 && stat != MVX_NS) {
+          if (stat == MVX_NF) {
+            code = 3;
+          } else {
+            const double abar = (stat == MVX_NL) ? -val : val;
+            if (kind != MVX_CV) {
+              const double fj = dev_fract(abar);
+              g = (fj <= f0) ? xdiv(fj, f0) : xdiv(1.0 - fj, 1.0 - f0);
+            } else {
+              g = (abar >= 0.0) ? xdiv(abar, f0) : xdiv(-abar, 1.0 - f0);
+            }
+            if (stat == MVX_NL) {
+              code = 1;
+              term = g * api_lb(lb);
+            } else {
+              code = 2;
+              term = -(g * api_ub(ub));
+            }
+          }
+        }
+        s_kind[t] = code;
+        s_aux[t] = term;
+        if (code == 1) work[var] = 0.0 + g;
+        if (code == 2) work[var] = 0.0 - g;
+      }
+    }
+    __syncthreads();
+    if (TIDX == 0) {
+      double rhs = s_rhs;
+      if (a.mode == 0) {
+        double temp = s_temp;
+        for (int t = 0; t < cnt; t++) {
+          const double val = s_val[t];
+          if (val == 0.0) continue; // glp_eval_tab_row returns the non-zeros only
+          const int kind = s_kind[t];
+          const double fRhs = dev_fract(rhs); // the RUNNING rhs (gmi.cpp:55,73)
+          const double fVal = dev_fract(val);
+          if (kind == MVX_IV) temp = (fRhs >= fVal) ? fVal : xdiv(fRhs, 1.0 - fRhs) * (1.0 - fVal);
+          if (kind == MVX_CV) temp = (val >= 0.0) ? val : xdiv(fRhs, 1.0 - fRhs) * (-1.0 * val);
+          work[s_var[t]] = -1.0 * temp; // gmi.cpp:72
+          rhs = rhs - temp * s_aux[t];  // gmi.cpp:73
+        }
+        s_temp = temp;
+      } else {
+        int bad = s_bad;
+        for (int t = 0; t < cnt; t++) {
+          const int code = s_kind[t];
+          if (code == 3) bad = 1;
+          if (code == 1 || code == 2) rhs = rhs + s_aux[t];
+        }
+        s_bad = bad;
+      }
+      s_rhs = rhs;
+    }
+    __syncthreads();
+  }
+  if (TIDX == 0) {
+    a.rhs[c] = s_rhs;
+    a.ok[c] = s_bad ? 0 : 1;
+  }
+}
+
+constexpr int GMI_CT = 4; // cuts per lane in the back-substitution (each loaded matrix entry serves four cuts)
+
+__global__ __launch_bounds__(256) void k_gmi_backsub(GmiArgs a) {
+  __shared__ double s_w[64][GMI_CT];
+  const int col = 1 + (int)blockIdx.x * 256 + TIDX;
+  const int c0 = (int)blockIdx.y * GMI_CT;
+  const bool act = col <= a.n;
+  double acc[GMI_CT];
+#pragma unroll
+  for (int u = 0; u < GMI_CT; u++) acc[u] = (act && c0 + u < a.count) ? a.work[(size_t)(c0 + u) * a.wld + a.m + col] : 0.0;
+  for (int i0 = 1; i0 <= a.m0; i0 += 64) {
+    __syncthreads();
+    {
+      const int r = TIDX >> 2, u = TIDX & 3; // 64 rows x 4 cuts
+      const int i = i0 + r;
+      s_w[r][u] = (i <= a.m0 && c0 + u < a.count) ? a.work[(size_t)(c0 + u) * a.wld + i] : 0.0;
+    }
+    __syncthreads();
+    const int cnt = (a.m0 - i0 + 1 < 64) ? a.m0 - i0 + 1 : 64;
+    if (act) {
+      for (int r = 0; r < cnt; r++) {
+        const int i = i0 + r;
+        const double av = a.A[(size_t)i * a.lda + col];
+        if (a.mode == 0) {
+          // position `col` of row i's non-zero list (gmi.cpp:87 indexes by position, not by column)
+          if (a.len && col > a.len[i]) continue;
+#pragma unroll
+          for (int u = 0; u < GMI_CT; u++) acc[u] = acc[u] + s_w[r][u] * av;
+        } else {
+          if (av == 0.0) continue;
+#pragma unroll
+          for (int u = 0; u < GMI_CT; u++)
+            if (s_w[r][u] != 0.0) acc[u] = acc[u] + s_w[r][u] * av;
+        }
+      }
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int u = 0; u < GMI_CT; u++)
+      if (c0 + u < a.count) a.out[(size_t)(c0 + u) * a.old + col] = acc[u];
+  }
+}
+
+void launch_gmi(const GmiArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_gmi_work, dim3((unsigned)a.count), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_gmi_backsub, dim3((unsigned)((a.n + 255) / 256), (unsigned)((a.count + GMI_CT - 1) / GMI_CT)), dim3(256), 0, s, a);
+}
+
 // ------------------------------------------------------------------ launch wrappers
 
 // tuning knobs of the streamed update (mvx_set_tuning; defaults are the measured best)

@@ -16,6 +16,7 @@
 
 #include "../../include/mvx.h"
 
+struct DevMatrix;
 namespace mvx {
 
 constexpr int ROWCOMB_CHUNK = 64; // rows per partial sum of k_rowcomb (fixed summation order)
@@ -108,6 +109,22 @@ struct CopyBatch {
   CopyJob jobs[COPY_BATCH];
 };
 
+// arguments of the GMI cut kernels (k_gmi_work / k_gmi_backsub): `count` cuts of one solved handle
+struct GmiArgs {
+  const double *T;     // tableau
+  const int *nvar, *nflag;
+  const double *nlb, *nub;
+  const int *kind;     // [n+1] column kinds of the model (MVX_CV / MVX_IV), device copy
+  const int *pos;      // [count] tableau row of each cut's basic column
+  double *work;        // [count][wld] coefficients by variable number 0..m+n (gmi.cpp:29-32 `work`)
+  double *rhs;         // [count]
+  int *ok;             // [count] 0 = no valid cut (repaired mode: free non-basic with a non-zero entry)
+  const double *A;     // [m0+1][lda] model rows 1..m0: packed non-zeros (bug-compatible) or by column (repaired)
+  const int *len;      // [m0+1] non-zeros per row (nullptr: every row dense)
+  double *out;         // [count][old] cut coefficients by structural column 1..n after rows 1..m0
+  int ld, m, n, wld, lda, m0, old, count, mode; // mode 0 bug-compatible (gmi.cpp:41-89), 1 repaired
+};
+
 // shared immutable matrix row (1-based, n+1 doubles)
 using RowPtr = std::shared_ptr<std::vector<double>>;
 
@@ -140,6 +157,9 @@ struct mvx_prob {
     double lb, ub;
   };
   std::vector<Edit> pending;
+  // device copy of model rows 1..m0 for the GMI back-substitution (gmi.cpp:81-89), shared by every clone whose first
+  // m0 rows are the same objects (B&B nodes share their root's rows); built on first use
+  std::shared_ptr<struct DevMatrix> dmat;
   // host mirrors of the basis (always in sync while valid)
   std::vector<int> bvar, nvar, nflag; // [m+1], [n+1], [n+1]
   std::vector<int> pos;               // pos[k], k=1..m+n: +row or -column
