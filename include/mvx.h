@@ -182,6 +182,11 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf);
 /* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
    for measurement sweeps -- results are identical for every setting */
 void mvx_set_tuning(int tr, int hot, int nt);
+/* resident-tableau path of primal phase 2 (cache-resident sizes: one launch keeps the tableau in LDS for the whole
+   run of pivots): 1 on, 0 off, -1 back to the default (on unless the environment has MVX_PERSIST=0).  Results are
+   identical either way.  mvx_persist_stats: launches made / launches that aborted and were redone by the two-kernel path */
+void mvx_set_persist(int mode);
+void mvx_persist_stats(long long *launches, long long *aborts);
 /* number of handles that share one launch in mvx_simplex_batch (default 64, 2..256) */
 void mvx_set_batch_slots(int slots);
 /* block until all work queued on the engine stream has finished */

@@ -23,6 +23,9 @@ _EXTRA = {
     "sync": (None, []),
     "set_tuning": (None, [C.c_int, C.c_int, C.c_int]),
     "set_batch_slots": (None, [C.c_int]),
+    "set_persist": (None, [C.c_int]),
+    "persist_stats": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "last_error": (C.c_int, []),
     "simplex_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "pack_size": (C.c_longlong, [C.c_void_p]),
     "pack": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -444,6 +444,8 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
 }
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
 void mvx_set_stall_limit(int limit) { mvx::set_stall_limit(limit); }
+void mvx_set_persist(int mode) { mvx::set_persist(mode); }
+void mvx_persist_stats(long long *launches, long long *aborts) { mvx::persist_stats(launches, aborts); }
 void mvx_set_batch_slots(int slots) { mvx::set_batch_slots(slots); }
 void mvx_profile_enable(int on) { mvx::profile_enable(on); }
 void mvx_profile_reset(void) { mvx::profile_reset(); }

@@ -51,6 +51,7 @@ void launch_fboot(Ctl *, int n, hipStream_t);
 void launch_fa(Ctl *, int n, hipStream_t);
 void launch_fb(Ctl *, int m, int n, hipStream_t);
 void launch_select(Ctl *, hipStream_t, int slots = 1);
+void launch_select_queue(Ctl *, const BatchQueue &q, hipStream_t, int slots);
 void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1);
 void launch_p1_head(Ctl *, hipStream_t);
 void launch_p1_select(Ctl *, hipStream_t);
@@ -58,6 +59,11 @@ void launch_p1_fix(Ctl *, int n, hipStream_t);
 void launch_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count, hipStream_t);
 void launch_copy_many(const CopyBatch &b, hipStream_t);
 void launch_gmi(const GmiArgs &a, hipStream_t);
+size_t persist_lds_bytes(int m, int cpw);
+int persist_max_cpw();
+int persist_msg_words(int m_cap);
+int launch_persist(Ctl *, unsigned long long *cand, unsigned long long *msg, int *abort_flag, int m, int cpw, int nw, int msg_stride,
+                   int max_steps, hipStream_t);
 void launch_rowcomb(Ctl *, int m, int n, int respect_done, hipStream_t);
 void launch_shift_nonbasic(double *T, int ld, int m, int jj, double delta, hipStream_t);
 void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub, hipStream_t);
@@ -89,6 +95,16 @@ struct SolveCtx {
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
   size_t stage_bytes = 0;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  // resident-tableau path (k_persist): candidate granules, pivot messages, abort flag; a backup of the slab, the
+  // control block and the devex weights taken in front of every launch, put back if the launch aborts
+  unsigned long long *d_pcand = nullptr, *d_pmsg = nullptr;
+  int *d_pabort = nullptr, *h_pabort = nullptr;
+  int p_msg_words = 0;
+  void *p_backup = nullptr;
+  size_t p_backup_bytes = 0;
+  Ctl *d_pctl = nullptr;
+  double *d_ppw = nullptr;
+  int p_pw_ld = 0;
 };
 
 // Slabs carved out of one multi-slab allocation (a growing B&B tree asks for one slab per open node: hipMalloc
@@ -670,6 +686,72 @@ static void flush_update_events(Context &c, size_t used) {
 
 // A solve is a small host-side state machine around queued launches, so that several of them
 // can be in flight on different streams (engine_simplex_batch): begin -> {enqueue, sync, collect}*.
+// ---- resident-tableau path (k_persist): which problems take it, its buffers, backup and restore
+static int g_persist_mode = -1;      // -1: environment MVX_PERSIST (default on), 0 off, 1 on
+static bool g_persist_broken = false; // a launch aborted (its workgroups were not co-resident in time): off for good
+static long long g_persist_launches = 0, g_persist_aborts = 0;
+struct PersistPlan {
+  int cpw = 0, nw = 0;
+  size_t lds = 0;
+};
+static bool persist_plan(Context &c, const mvx_prob *P, PersistPlan *pl) {
+  if (g_persist_broken) return false;
+  if (g_persist_mode < 0) {
+    const char *e = std::getenv("MVX_PERSIST");
+    g_persist_mode = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!g_persist_mode) return false;
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c.dev) != hipSuccess) return false;
+    cus = prop.multiProcessorCount;
+  }
+  const int m = P->m, n = P->n;
+  if ((long)(m + 1) * (n + 1) < 32768) return false; // a handful of pivots: the launch is not worth its set-up
+  const int cpw = (n + cus - 1) / cus;
+  if (cpw > persist_max_cpw()) return false;
+  pl->cpw = cpw;
+  pl->nw = (n + cpw - 1) / cpw; // one workgroup per CU at most: every workgroup must be resident at once
+  pl->lds = persist_lds_bytes(m, cpw);
+  return pl->lds <= (size_t)150 * 1024;
+}
+
+static bool ensure_persist(Context &c, SolveCtx &sc, const mvx_prob *P, const PersistPlan &pl) {
+  const int words = persist_msg_words(P->m_cap);
+  if (!sc.d_pabort) {
+    HIPCHECK(hipMalloc((void **)&sc.d_pabort, 256));
+    HIPCHECK(hipMemsetAsync(sc.d_pabort, 0, 256, sc.stream));
+    HIPCHECK(hipHostMalloc((void **)&sc.h_pabort, 256));
+    sc.h_pabort[0] = 0;
+    HIPCHECK(hipMalloc((void **)&sc.d_pcand, (size_t)2 * 256 * 3 * 8 * 4));
+    HIPCHECK(hipMalloc((void **)&sc.d_pctl, sizeof(Ctl)));
+  }
+  if (words > sc.p_msg_words) {
+    HIPCHECK(hipStreamSynchronize(sc.stream));
+    if (sc.d_pmsg) HIPCHECK(hipFree(sc.d_pmsg));
+    HIPCHECK(hipMalloc((void **)&sc.d_pmsg, (size_t)2 * words * 8));
+    sc.p_msg_words = words;
+  }
+  if (P->ld > sc.p_pw_ld) {
+    HIPCHECK(hipStreamSynchronize(sc.stream));
+    if (sc.d_ppw) HIPCHECK(hipFree(sc.d_ppw));
+    HIPCHECK(hipMalloc((void **)&sc.d_ppw, (size_t)2 * P->ld * 8));
+    sc.p_pw_ld = P->ld;
+  }
+  if (sc.p_backup_bytes != P->slab_bytes) {
+    if (sc.p_backup) slab_recycle(c, sc.p_backup, sc.p_backup_bytes);
+    sc.p_backup = slab_alloc(c, P->slab_bytes);
+    sc.p_backup_bytes = sc.p_backup ? P->slab_bytes : 0;
+    if (!sc.p_backup) {
+      (void)g_last_error.exchange(0); // not an error of the caller's: the two-kernel path serves
+      return false;
+    }
+  }
+  (void)pl;
+  return true;
+}
+
 struct SolveJob {
   mvx_prob *P = nullptr;
   SolveCtx *sc = nullptr;
@@ -678,6 +760,7 @@ struct SolveJob {
   int batch = 8, pb = 4;
   int done = D_RUN;
   bool try_fused = false;
+  bool persist_queued = false; // this batch of launches contains a k_persist launch (its abort flag is copied back)
   int seen_steps = 0, seen_pivots = 0;
   size_t ev_used = 0;
   bool profiled = false;
@@ -694,6 +777,7 @@ static int pivot_budget(const mvx_prob *P, const mvx_smcp &parm) {
 static void stage_copy_async(SolveCtx &sc, const mvx_prob *P) {
   HIPCHECK(hipEventRecord(sc.ev_b, sc.stream)); // end of the device work queued so far (last_solve_ms)
   HIPCHECK(hipMemcpyAsync(sc.h_stage, sc.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, sc.stream));
+  if (sc.d_pabort) HIPCHECK(hipMemcpyAsync(sc.h_pabort, sc.d_pabort, sizeof(int), hipMemcpyDeviceToHost, sc.stream));
 }
 
 static void job_begin(Context &c, SolveJob &J) {
@@ -766,7 +850,28 @@ static void job_enqueue(Context &c, SolveJob &J) {
       ev();
       launch_update(sc.d_ctl, m_grid, n, sc.stream);
       ev();
-      if (depth > 0) {
+      PersistPlan pl;
+      if (depth > 0 && !J.profiled && persist_plan(c, P, &pl) && ensure_persist(c, sc, P, pl)) {
+        // cache-resident size: the whole run of primal pivots in ONE launch with the tableau held in LDS.  In front
+        // of it a backup (slab, control block, both devex weight sets): a launch whose workgroups do not all become
+        // resident in time aborts mid-step, and the backup is what the two-kernel path then carries on from.
+        HIPCHECK(hipMemcpyAsync(sc.p_backup, P->slab, P->slab_bytes, hipMemcpyDeviceToDevice, sc.stream));
+        HIPCHECK(hipMemcpyAsync(sc.d_pctl, sc.d_ctl, sizeof(Ctl), hipMemcpyDeviceToDevice, sc.stream));
+        HIPCHECK(hipMemcpyAsync(sc.d_ppw, sc.d_pw[0], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
+        HIPCHECK(hipMemcpyAsync(sc.d_ppw + P->ld, sc.d_pw[1], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
+        HIPCHECK(hipMemsetAsync(sc.d_pcand, 0, (size_t)2 * pl.nw * 3 * 8, sc.stream));
+        HIPCHECK(hipMemsetAsync(sc.d_pmsg, 0, (size_t)2 * sc.p_msg_words * 8, sc.stream));
+        const int steps = 1 << 24; // the pivot limit is the control block's `budget`, which the kernel counts down
+        if (launch_persist(sc.d_ctl, sc.d_pcand, sc.d_pmsg, sc.d_pabort, P->m, pl.cpw, pl.nw, sc.p_msg_words, steps, sc.stream) == 0) {
+          J.persist_queued = true;
+          g_persist_launches++;
+          // what the run ended on (optimum, unbounded ray, stall, pivot limit) is settled by one generic step
+          launch_select(sc.d_ctl, sc.stream);
+          launch_update(sc.d_ctl, m_grid, n, sc.stream);
+        } else {
+          g_persist_broken = true;
+        }
+      } else if (depth > 0) {
         launch_fboot(sc.d_ctl, n, sc.stream);
         launch_fb(sc.d_ctl, m_grid, n, sc.stream);
         for (int k = 0; k < depth; k++) {
@@ -833,6 +938,25 @@ static bool job_finalize(SolveJob &J) {
 static bool job_collect(Context &c, SolveJob &J) {
   SolveCtx &sc = *J.sc;
   Ctl &snap = J.snap;
+  if (J.persist_queued) {
+    J.persist_queued = false;
+    if (sc.h_pabort[0]) {
+      // the resident-tableau launch gave up waiting for its peers: its workgroups may have stopped one step apart,
+      // so the tableau is put back as it was in front of the launch and the two-kernel path carries on from there
+      mvx_prob *P = J.P;
+      g_persist_broken = true;
+      g_persist_aborts++;
+      std::fprintf(stderr, "mvx: resident-tableau launch aborted (workgroups not co-resident in time); using the two-kernel path from now on\n");
+      HIPCHECK(hipMemcpyAsync(P->slab, sc.p_backup, P->slab_bytes, hipMemcpyDeviceToDevice, sc.stream));
+      HIPCHECK(hipMemcpyAsync(sc.d_ctl, sc.d_pctl, sizeof(Ctl), hipMemcpyDeviceToDevice, sc.stream));
+      HIPCHECK(hipMemcpyAsync(sc.d_pw[0], sc.d_ppw, (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
+      HIPCHECK(hipMemcpyAsync(sc.d_pw[1], sc.d_ppw + P->ld, (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
+      HIPCHECK(hipMemsetAsync(sc.d_pabort, 0, sizeof(int), sc.stream));
+      sc.h_pabort[0] = 0;
+      J.try_fused = true; // the backup was taken right after a generic step in primal phase 2
+      return false;
+    }
+  }
   std::memcpy(&snap, sc.h_stage, sizeof(Ctl));
   if (J.mode == SolveJob::FINAL) return job_finalize(J);
   if (J.mode == SolveJob::PHASE1) {
@@ -949,110 +1073,115 @@ int engine_simplex(mvx_prob *P, const mvx_smcp *parm) { return engine_simplex_on
 
 // ------------------------------------------------------------------------ batched solves
 // Independent node LPs (the two children of a branch, a window of open B&B nodes) advance together:
-// ONE launch of k_select / k_update carries every handle of the batch (grid.z = slot), each slot
-// with its own control block, scratch and staging area.  Small tableaux are bound by the dispatch
-// rate of tiny kernels (measured: 8 streams give only ~1.7x), so the slots share launches instead
-// of competing for them.  Results are bit-identical to one mvx_simplex call per handle: every
-// slot runs the same generic state machine (k_select) on its own data.
+// ONE launch of k_select / k_update carries every slot of the batch (grid.z = slot), each slot
+// with its own control block and scratch.  Small tableaux are bound by the dispatch rate of tiny
+// kernels (measured: 8 streams give only ~1.7x), so the slots share launches instead of competing
+// for them.  The handles form a work queue on the device: the host uploads one control block per handle
+// and the slots pull them (k_select: a slot whose solve has ended exports its mirrors into the job's
+// staging area and takes the next job in the very launch that finds it idle), so slots do not sit
+// idle until the host's next synchronisation point -- the host only polls two counters.  Results are
+// bit-identical to one mvx_simplex call per handle: every job runs the same generic state machine
+// (k_select) on its own data.
 struct BatchCtx {
-  int slots = 0;
+  int slots = 0, jobs = 0;
   int m_cap = 0, ld = 0; // per-slot scratch capacity
   hipStream_t stream = nullptr;
-  Ctl *d_ctl = nullptr, *h_ctl = nullptr;
-  Ctl *d_fill = nullptr, *h_fill = nullptr; // packed control blocks of the slots filled at one sync point
-  int *d_fidx = nullptr, *h_fidx = nullptr; // ... and their slot numbers
+  Ctl *d_ctl = nullptr, *h_ctl = nullptr;   // slot control blocks (host copy: the idle pattern)
+  Ctl *d_jobs = nullptr, *h_jobs = nullptr; // job control blocks
+  SlotScratch *d_sp = nullptr, *h_sp = nullptr;
+  int *d_cnt = nullptr, *h_cnt = nullptr; // [0] next job, [1] finished jobs
   unsigned char *scratch = nullptr;
   size_t scratch_stride = 0;
-  unsigned char *d_stage = nullptr, *h_stage = nullptr;
+  unsigned char *d_stage = nullptr, *h_stage = nullptr; // one staging area per JOB
   size_t stage_stride = 0;
 };
 static BatchCtx g_batch;
+static std::mutex g_batch_mu; // one batched solve at a time
 static void sync_batch_stream() {
   if (g_batch.stream) HIPCHECK(hipStreamSynchronize(g_batch.stream));
 }
 static int g_batch_slots = 64;
 
-static void ensure_batch(BatchCtx &bc, int slots, int m_cap, int ld) {
+static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
   if (!bc.stream) HIPCHECK(hipStreamCreateWithFlags(&bc.stream, hipStreamNonBlocking));
-  if (slots <= bc.slots && m_cap <= bc.m_cap && ld <= bc.ld) return;
+  if (slots <= bc.slots && jobs <= bc.jobs && m_cap <= bc.m_cap && ld <= bc.ld) return;
   HIPCHECK(hipStreamSynchronize(bc.stream));
   if (bc.d_ctl) HIPCHECK(hipFree(bc.d_ctl));
   if (bc.h_ctl) HIPCHECK(hipHostFree(bc.h_ctl));
-  if (bc.d_fill) HIPCHECK(hipFree(bc.d_fill));
-  if (bc.h_fill) HIPCHECK(hipHostFree(bc.h_fill));
-  if (bc.d_fidx) HIPCHECK(hipFree(bc.d_fidx));
-  if (bc.h_fidx) HIPCHECK(hipHostFree(bc.h_fidx));
+  if (bc.d_jobs) HIPCHECK(hipFree(bc.d_jobs));
+  if (bc.h_jobs) HIPCHECK(hipHostFree(bc.h_jobs));
+  if (bc.d_sp) HIPCHECK(hipFree(bc.d_sp));
+  if (bc.h_sp) HIPCHECK(hipHostFree(bc.h_sp));
+  if (bc.d_cnt) HIPCHECK(hipFree(bc.d_cnt));
+  if (bc.h_cnt) HIPCHECK(hipHostFree(bc.h_cnt));
   if (bc.scratch) HIPCHECK(hipFree(bc.scratch));
   if (bc.d_stage) HIPCHECK(hipFree(bc.d_stage));
   if (bc.h_stage) HIPCHECK(hipHostFree(bc.h_stage));
   bc.slots = std::max(slots, bc.slots);
+  bc.jobs = std::max(jobs + jobs / 2, bc.jobs);
   bc.m_cap = std::max(m_cap, bc.m_cap);
   bc.ld = std::max(ld, bc.ld);
   HIPCHECK(hipMalloc((void **)&bc.d_ctl, sizeof(Ctl) * bc.slots));
   HIPCHECK(hipHostMalloc((void **)&bc.h_ctl, sizeof(Ctl) * bc.slots));
-  HIPCHECK(hipMalloc((void **)&bc.d_fill, sizeof(Ctl) * bc.slots));
-  HIPCHECK(hipHostMalloc((void **)&bc.h_fill, sizeof(Ctl) * bc.slots));
-  HIPCHECK(hipMalloc((void **)&bc.d_fidx, sizeof(int) * bc.slots));
-  HIPCHECK(hipHostMalloc((void **)&bc.h_fidx, sizeof(int) * bc.slots));
-  bc.scratch_stride = align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256) +
-                      2 * align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) + align_up((size_t)(bc.m_cap + 1) * 8, 256) +
-                      align_up((size_t)bc.ld * 8, 256);
+  HIPCHECK(hipMalloc((void **)&bc.d_jobs, sizeof(Ctl) * bc.jobs));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_jobs, sizeof(Ctl) * bc.jobs));
+  HIPCHECK(hipMalloc((void **)&bc.d_sp, sizeof(SlotScratch) * bc.slots));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_sp, sizeof(SlotScratch) * bc.slots));
+  HIPCHECK(hipMalloc((void **)&bc.d_cnt, sizeof(int) * 4));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_cnt, sizeof(int) * 4));
+  const size_t s_row = align_up((size_t)(bc.m_cap + 1) * 8, 256), s_col = align_up((size_t)bc.ld * 8, 256);
+  const size_t s_var = align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256);
+  bc.scratch_stride = s_row + s_col + 2 * s_var + s_row + s_col;
   HIPCHECK(hipMalloc((void **)&bc.scratch, bc.scratch_stride * bc.slots));
   HIPCHECK(hipMemsetAsync(bc.scratch, 0, bc.scratch_stride * bc.slots, bc.stream));
+  for (int k = 0; k < bc.slots; k++) {
+    unsigned char *sb = bc.scratch + (size_t)k * bc.scratch_stride;
+    SlotScratch &sp = bc.h_sp[k];
+    sp.colq = (double *)sb;
+    sp.srow = (double *)(sb + s_row);
+    sp.olb = (double *)(sb + s_row + s_col);
+    sp.oub = (double *)(sb + s_row + s_col + s_var);
+    sp.dw = (double *)(sb + s_row + s_col + 2 * s_var);
+    sp.pw = (double *)(sb + s_row + s_col + 2 * s_var + s_row); // generic path only: one set of primal weights
+  }
+  HIPCHECK(hipMemcpyAsync(bc.d_sp, bc.h_sp, sizeof(SlotScratch) * bc.slots, hipMemcpyHostToDevice, bc.stream));
   bc.stage_stride = stage_size(bc.m_cap, bc.ld);
-  HIPCHECK(hipMalloc((void **)&bc.d_stage, bc.stage_stride * bc.slots));
-  HIPCHECK(hipHostMalloc((void **)&bc.h_stage, bc.stage_stride * bc.slots));
-  // idle slots must read as finished
+  HIPCHECK(hipMalloc((void **)&bc.d_stage, bc.stage_stride * bc.jobs));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_stage, bc.stage_stride * bc.jobs));
+  // an idle slot reads as finished and holds no job
   std::memset(bc.h_ctl, 0, sizeof(Ctl) * bc.slots);
-  for (int k = 0; k < bc.slots; k++) bc.h_ctl[k].done = D_FAIL;
-  HIPCHECK(hipMemcpyAsync(bc.d_ctl, bc.h_ctl, sizeof(Ctl) * bc.slots, hipMemcpyHostToDevice, bc.stream));
+  for (int k = 0; k < bc.slots; k++) {
+    bc.h_ctl[k].done = D_FAIL;
+    bc.h_ctl[k].job = -1;
+  }
 }
 
-static void batch_fill_slot(BatchCtx &bc, int k, mvx_prob *P, const mvx_smcp &parm) {
-  Ctl *h = &bc.h_ctl[k];
+// control block of one job; the slot that pulls it points it at its own scratch (k_select)
+static void batch_fill_job(Ctl *h, mvx_prob *P, const mvx_smcp &parm) {
   std::memset(h, 0, sizeof(Ctl));
-  unsigned char *sb = bc.scratch + (size_t)k * bc.scratch_stride;
   h->T = P->d_T;
   h->bvar = P->d_bvar; h->blb = P->d_blb; h->bub = P->d_bub;
   h->nvar = P->d_nvar; h->nflag = P->d_nflag; h->nlb = P->d_nlb; h->nub = P->d_nub;
-  h->colq = (double *)sb;
-  h->srow = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256));
-  h->olb = (double *)(sb + align_up((size_t)(bc.m_cap + 1) * 8, 256) + align_up((size_t)bc.ld * 8, 256));
-  h->oub = h->olb + align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) / 8;
-  h->dw = h->oub + align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256) / 8;
-  h->pw[0] = h->pw[1] = h->dw + align_up((size_t)(bc.m_cap + 1) * 8, 256) / 8; // generic path only: one set
   h->m = P->m; h->n = P->n; h->ld = P->ld; h->m_cap = P->m_cap;
   h->sgn = (P->dir == MVX_MAX) ? 1.0 : -1.0;
   h->tol_bnd = parm.tol_bnd; h->tol_dj = parm.tol_dj; h->tol_piv = parm.tol_piv;
   h->phase = PH_START; h->done = D_RUN; h->budget = pivot_budget(P, parm);
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->fstate = F_OFF;
+  h->job = -1;
   take_edits(P, h);
 }
 
-// upload the control blocks of the slots filled since the last flush (host side: bc.h_ctl[k])
-static void batch_flush_fills(BatchCtx &bc, std::vector<int> &fills) {
-  const int cnt = (int)fills.size();
-  if (cnt == 1) {
-    const int k = fills[0];
-    HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], &bc.h_ctl[k], sizeof(Ctl), hipMemcpyHostToDevice, bc.stream));
-  } else if (cnt > 1) {
-    for (int t = 0; t < cnt; t++) {
-      bc.h_fill[t] = bc.h_ctl[fills[(size_t)t]];
-      bc.h_fidx[t] = fills[(size_t)t];
-    }
-    HIPCHECK(hipMemcpyAsync(bc.d_fill, bc.h_fill, sizeof(Ctl) * (size_t)cnt, hipMemcpyHostToDevice, bc.stream));
-    HIPCHECK(hipMemcpyAsync(bc.d_fidx, bc.h_fidx, sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice, bc.stream));
-    launch_scatter_ctl(bc.d_ctl, bc.d_fill, bc.d_fidx, cnt, bc.stream);
-  }
-  fills.clear();
-}
-
-// mirrors + status of a finished slot; layout inside the slot follows the handle's own m_cap / ld
-static int batch_finish_slot(BatchCtx &bc, int k, mvx_prob *P) {
-  const unsigned char *s = bc.h_stage + (size_t)k * bc.stage_stride;
+// mirrors + status of a finished job; layout inside the staging area follows the handle's own m_cap / ld
+static int batch_finish_job(BatchCtx &bc, int j, mvx_prob *P, int *done_code) {
+  const unsigned char *s = bc.h_stage + (size_t)j * bc.stage_stride;
   Ctl snap;
   std::memcpy(&snap, s, sizeof(Ctl));
+  *done_code = snap.done;
+  P->it_cnt += snap.it_cnt;
+  P->bland_cnt += snap.n_bland;
+  P->pert_cnt += snap.n_pert;
+  if (snap.done == D_NEED_PHASE1) return 0; // neither primal nor dual feasible: the caller finishes it on the single-handle path
   const double *beta = (const double *)(s + sizeof(Ctl));
   const double *dj = beta + (P->m_cap + 1);
   const int *bv = (const int *)(dj + P->ld);
@@ -1066,9 +1195,6 @@ static int batch_finish_slot(BatchCtx &bc, int k, mvx_prob *P) {
   rebuild_pos(P);
   P->sol_fresh = true;
   P->last_ms = 0.0;
-  P->it_cnt += snap.it_cnt;
-  P->bland_cnt += snap.n_bland;
-  P->pert_cnt += snap.n_pert;
   P->hint_dual = false;
   switch (snap.done) {
     case D_OPT: P->status = MVX_OPT; return 0;
@@ -1123,76 +1249,45 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     return 0;
   }
   if (pending.empty()) return 0;
+  std::lock_guard<std::mutex> batch_lock(g_batch_mu);
   BatchCtx &bc = g_batch;
-  const int K = std::min((int)pending.size(), g_batch_slots);
-  ensure_batch(bc, K, m_cap, ld);
+  const int njobs = (int)pending.size();
+  const int K = std::min(njobs, g_batch_slots);
+  ensure_batch(bc, K, njobs, m_cap, ld);
   // edits queued on the main stream (bound changes, clones) must be visible to the batch stream
   HIPCHECK(hipStreamSynchronize(c.main.stream));
-  std::vector<int> slot((size_t)bc.slots, -1);
-  size_t next = 0;
-  int active = 0;
-  std::vector<int> fills;
-  for (int k = 0; k < K && next < pending.size(); k++) {
-    slot[(size_t)k] = pending[next++];
-    batch_fill_slot(bc, k, probs[slot[(size_t)k]], parm);
-    fills.push_back(k);
-    active++;
-  }
-  batch_flush_fills(bc, fills);
-  int depth = 8; // queue-ahead depth per sync: 8, 16, 32 (a sweep of 4..16 / 8..64 moved B&B throughput by < 3 %)
-  int Kact = K;  // occupied slots are kept in positions 0..Kact-1: a launch carries no idle slot
-  while (active > 0) {
-    // (two half-batches on two streams were measured: no gain -- kernels of different streams do
-    // not overlap usefully here, the update is bandwidth-bound and the select is tiny)
+  for (int j = 0; j < njobs; j++) batch_fill_job(&bc.h_jobs[j], probs[pending[(size_t)j]], parm);
+  bc.h_cnt[0] = bc.h_cnt[1] = 0;
+  HIPCHECK(hipMemcpyAsync(bc.d_jobs, bc.h_jobs, sizeof(Ctl) * (size_t)njobs, hipMemcpyHostToDevice, bc.stream));
+  HIPCHECK(hipMemcpyAsync(bc.d_ctl, bc.h_ctl, sizeof(Ctl) * (size_t)K, hipMemcpyHostToDevice, bc.stream)); // every slot idle
+  HIPCHECK(hipMemcpyAsync(bc.d_cnt, bc.h_cnt, sizeof(int) * 2, hipMemcpyHostToDevice, bc.stream));
+  BatchQueue q;
+  q.jobs = bc.d_jobs;
+  q.scratch = bc.d_sp;
+  q.counters = bc.d_cnt;
+  q.stage = bc.d_stage;
+  q.stage_stride = bc.stage_stride;
+  q.count = njobs;
+  // queue-ahead depth per poll: the slots refill themselves, so a poll only has to notice the end
+  int depth = njobs <= 2 ? 8 : 16;
+  for (;;) {
     for (int d = 0; d < depth; d++) {
-      launch_select(bc.d_ctl, bc.stream, Kact);
-      launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact);
+      launch_select_queue(bc.d_ctl, q, bc.stream, K);
+      launch_update(bc.d_ctl, m_max, n_max, bc.stream, K);
     }
-    launch_export(bc.d_ctl, bc.d_stage, m_max, n_max, 0, bc.stream, Kact, bc.stage_stride);
-    HIPCHECK(hipMemcpyAsync(bc.h_stage, bc.d_stage, bc.stage_stride * Kact, hipMemcpyDeviceToHost, bc.stream));
+    HIPCHECK(hipMemcpyAsync(bc.h_cnt + 2, bc.d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, bc.stream));
     HIPCHECK(hipStreamSynchronize(bc.stream));
-    for (int k = 0; k < Kact; k++) {
-      const int i = slot[(size_t)k];
-      if (i < 0) continue;
-      Ctl snap;
-      std::memcpy(&snap, bc.h_stage + (size_t)k * bc.stage_stride, sizeof(Ctl));
-      if (snap.done == D_RUN) continue;
-      if (snap.done == D_NEED_PHASE1) {
-        fallback.push_back(i); // neither primal nor dual feasible: finish on the single-handle path
-        probs[i]->it_cnt += snap.it_cnt;
-        probs[i]->bland_cnt += snap.n_bland;
-        probs[i]->pert_cnt += snap.n_pert;
-      } else {
-        const int rc = batch_finish_slot(bc, k, probs[i]);
-        if (rcs) rcs[i] = rc;
-      }
-      active--;
-      slot[(size_t)k] = -1;
-      if (next < pending.size()) {
-        slot[(size_t)k] = pending[next++];
-        batch_fill_slot(bc, k, probs[slot[(size_t)k]], parm);
-        fills.push_back(k);
-        active++;
-      }
-    }
-    batch_flush_fills(bc, fills);
-    // Nothing left to refill with: close the gaps.  The grid of every launch is sized for its slots, and an
-    // idle slot of a large tableau still costs thousands of workgroups that start only to leave (4096x8192:
-    // 4369 per slot, ~5 us), so the control block of the last occupied slot moves into each hole.  Its
-    // pointers keep addressing the scratch area it was given.
-    for (int k = 0; k < Kact; k++) {
-      if (slot[(size_t)k] >= 0) continue;
-      int j = Kact - 1;
-      while (j > k && slot[(size_t)j] < 0) j--;
-      if (j > k) {
-        HIPCHECK(hipMemcpyAsync(&bc.d_ctl[k], &bc.d_ctl[j], sizeof(Ctl), hipMemcpyDeviceToDevice, bc.stream));
-        bc.h_ctl[k] = bc.h_ctl[j];
-        slot[(size_t)k] = slot[(size_t)j];
-        slot[(size_t)j] = -1;
-      }
-      Kact = j > k ? j : k;
-    }
+    if (bc.h_cnt[3] >= njobs) break;
     depth = std::min(depth * 2, 32);
+  }
+  HIPCHECK(hipMemcpyAsync(bc.h_stage, bc.d_stage, bc.stage_stride * (size_t)njobs, hipMemcpyDeviceToHost, bc.stream));
+  HIPCHECK(hipStreamSynchronize(bc.stream));
+  for (int j = 0; j < njobs; j++) {
+    const int i = pending[(size_t)j];
+    int code = 0;
+    const int rc = batch_finish_job(bc, j, probs[i], &code);
+    if (code == D_NEED_PHASE1) fallback.push_back(i);
+    else if (rcs) rcs[i] = rc;
   }
   for (int i : fallback) {
     // the batch left this handle untouched apart from zero or more completed pivots
@@ -1220,7 +1315,10 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
         merged = true;
       }
     if (!merged) {
-      if ((int)P->pending.size() == MAX_EDITS) flush_edits(sc, P);
+      if ((int)P->pending.size() == MAX_EDITS) {
+        flush_copies(c); // a recorded clone INTO this handle's slab must land before the edits do
+        flush_edits(sc, P);
+      }
       P->pending.push_back({pos, lb, ub});
     }
     P->hint_dual = true; // a basic variable's bound moved: the warm start is a dual one (bs.cpp:274,282)
@@ -1725,6 +1823,14 @@ void tuning(int tr, int hot, int nt) {
   }
 }
 
+void set_persist(int mode) {
+  g_persist_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  g_persist_broken = false;
+}
+void persist_stats(long long *launches, long long *aborts) {
+  *launches = g_persist_launches;
+  *aborts = g_persist_aborts;
+}
 void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }
 void profile_enable(int on) { ctx().prof = on != 0; }

@@ -36,6 +36,8 @@ int engine_pack(const mvx_prob *P, int m_base, void *dev_buf);
 int engine_unpack(mvx_prob *dst, const void *dev_buf);
 void tuning(int tr, int hot, int nt);
 void set_stall_limit(int limit);
+void set_persist(int mode);
+void persist_stats(long long *launches, long long *aborts);
 void set_batch_slots(int k);
 void profile_enable(int on);
 void profile_reset();

@@ -420,9 +420,7 @@ __device__ __forceinline__ void dev_finish(Ctl *c, int code, int phase, int roun
 
 // ---------------------------------------------------------------------------- k_select
 // Device-side restatement of orc_simplex's round loop + one pricing / ratio-test step.
-__global__ __launch_bounds__(1024) void k_select(Ctl *c) {
-  __shared__ Cand lds[17];
-  c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
+__device__ void select_step(Ctl *c, Cand *lds) {
   const KC k = load_kc(c); // every pointer / constant the step needs, fetched in one burst
   if (c->done != D_RUN) return;
   const int ne = c->n_edits;
@@ -569,6 +567,71 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c) {
     c->phase = phase;
     c->rounds = rounds;
   }
+}
+
+// What the host needs after a solve, packed into one staging area (all threads of the block call):
+//   [Ctl][beta (m_cap+1) f64][d (ld) f64][bvar (m_cap+1) i32][nvar (ld) i32][nflag (ld) i32]
+__device__ void pack_mirrors(const Ctl *c, unsigned char *stage, int t0, int step) {
+  const int m = c->m, n = c->n, ld = c->ld, mc = c->m_cap;
+  double *beta = reinterpret_cast<double *>(stage + sizeof(Ctl));
+  double *dj = beta + (mc + 1);
+  int *bv = reinterpret_cast<int *>(dj + ld);
+  int *nv = bv + (mc + 1);
+  int *nf = nv + ld;
+  for (int t = t0; t <= m || t <= n; t += step) {
+    if (t <= m) {
+      beta[t] = c->T[(size_t)t * ld];
+      bv[t] = c->bvar[t];
+    }
+    if (t <= n) {
+      dj[t] = c->T[t];
+      nv[t] = c->nvar[t];
+      nf[t] = c->nflag[t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
+  __shared__ Cand lds[17];
+  __shared__ int s_job;
+  c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
+  if (q.jobs && c->done != D_RUN) {
+    // this slot's solve has ended (or it never had one): hand the finished job over and pull the next
+    const int old = c->job;
+    if (old >= 0) {
+      unsigned char *st = q.stage + (size_t)old * q.stage_stride;
+      pack_mirrors(c, st, TIDX, 1024);
+      const unsigned *src = reinterpret_cast<const unsigned *>(c);
+      unsigned *dst = reinterpret_cast<unsigned *>(st);
+      for (int w = TIDX; w < (int)(sizeof(Ctl) / 4); w += 1024) dst[w] = src[w];
+    }
+    __syncthreads();
+    if (TIDX == 0) {
+      if (old >= 0) {
+        __threadfence(); // the staging area is complete before the job counts as finished
+        atomicAdd(&q.counters[1], 1);
+      }
+      s_job = (q.counters[0] < q.count) ? atomicAdd(&q.counters[0], 1) : q.count;
+    }
+    __syncthreads();
+    const int j = s_job;
+    if (j >= q.count) {
+      if (TIDX == 0) c->job = -1;
+      return;
+    }
+    const unsigned *src = reinterpret_cast<const unsigned *>(&q.jobs[j]);
+    unsigned *dst = reinterpret_cast<unsigned *>(c);
+    for (int w = TIDX; w < (int)(sizeof(Ctl) / 4); w += 1024) dst[w] = src[w];
+    __syncthreads();
+    if (TIDX == 0) {
+      const SlotScratch sp = q.scratch[blockIdx.z];
+      c->colq = sp.colq; c->srow = sp.srow; c->olb = sp.olb; c->oub = sp.oub; c->dw = sp.dw;
+      c->pw[0] = c->pw[1] = sp.pw;
+      c->job = j;
+    }
+    __syncthreads();
+  }
+  select_step(c, lds);
 }
 
 // ------------------------------------------------------------------------ phase-1 kernels
@@ -876,21 +939,7 @@ __global__ __launch_bounds__(256) void k_export(Ctl *c, unsigned char *stage, in
   if (t == 0) *reinterpret_cast<Ctl *>(stage) = *c;
   if (c->T == nullptr) return; // idle slot of a batched launch
   if (!force && c->done == D_RUN) return;
-  const int m = c->m, n = c->n, ld = c->ld, mc = c->m_cap;
-  double *beta = reinterpret_cast<double *>(stage + sizeof(Ctl));
-  double *dj = beta + (mc + 1);
-  int *bv = reinterpret_cast<int *>(dj + ld);
-  int *nv = bv + (mc + 1);
-  int *nf = nv + ld;
-  if (t <= m) {
-    beta[t] = c->T[(size_t)t * ld];
-    bv[t] = c->bvar[t];
-  }
-  if (t <= n) {
-    dj[t] = c->T[t];
-    nv[t] = c->nvar[t];
-    nf[t] = c->nflag[t];
-  }
+  pack_mirrors(c, stage, t, (int)gridDim.x * 256);
 }
 
 // ======================================================================= fused primal path
@@ -1261,6 +1310,333 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   }
 }
 
+// ======================================================================= resident-tableau primal path
+// Cache-resident sizes (1024x2048: 16.8 MB; every 512x1024 node LP) are bound by launch latency, not by
+// bandwidth: two dependent launches per pivot cost ~14 us where the bytes would take ~4.  k_persist keeps
+// the whole tableau ON CHIP for hundreds of pivots: one launch, one workgroup per CU, each owning a strip
+// of CPW consecutive columns in its LDS (column-major, so that a lane walks rows conflict-free), plus its
+// own replica of column 0 (basic values) and of the per-row metadata (basic variable, bounds).  Per pivot
+// only three things cross workgroups, through agent-scope 8-byte atomics (MI355X_MICROARCH.md, inter-
+// workgroup visibility: "8-B agent atomics both sides" / sc1 payload + drained flag):
+//   1. every workgroup's best entering candidate of its strip (three self-tagged granules), gathered by all;
+//   2. from the workgroup that owns the chosen column q: the pivot description and column q itself;
+// everything else -- scaled pivot-row entries, the rank-1 update of the strip, devex weights, the next
+// pricing -- is local.  The next candidate is published BEFORE the bulk update of the strip, so the gather
+// overlaps it.  Arithmetic per entry is that of k_fa / k_fb / the oracle; every wait is bounded and ends in
+// a shared abort flag, so the grid always drains (the host then falls back on k_fa / k_fb for good).
+struct PersistArgs {
+  Ctl *ctl;
+  unsigned long long *cand; // [2][nw][3] tagged candidate granules
+  unsigned long long *msg;  // [2][PMSG_HDR + m_cap + 1] pivot message: flag, header, column q
+  int *abort_flag;
+  int cpw, nw, msg_stride, max_steps;
+};
+constexpr int PMSG_HDR = 16; // u64 words in front of the column in a pivot message (word 0 = flag)
+constexpr int PERSIST_SPIN = 1 << 21;
+constexpr int PERSIST_MAX_CPW = 16;
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long d2u(double x) { return (unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ double u2d(unsigned long long x) { return __longlong_as_double((long long)x); }
+
+// one lane waits until *p carries `want` in its high word (bounded); false = abort
+__device__ __forceinline__ bool wait_tag(const unsigned long long *p, unsigned want, const int *abort_flag, unsigned long long *out) {
+  for (int spin = 0; spin < PERSIST_SPIN; spin++) {
+    const unsigned long long v = ld_agent(p);
+    if ((unsigned)(v >> 32) == want) {
+      *out = v;
+      return true;
+    }
+    if ((spin & 255) == 255) {
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
+  extern __shared__ double smem[];
+  __shared__ Cand lds[17];
+  __shared__ unsigned long long s_hdr[PMSG_HDR];
+  __shared__ int s_ok;
+  Ctl *c = a.ctl;
+  if (c->done != D_RUN || c->phase != PH_PRIMAL2 || c->stall >= c->stall_limit || c->budget == 0 || c->perturbed) return;
+  if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  const int m = c->m, n = c->n, cpw = a.cpw, w = (int)blockIdx.x;
+  const size_t ld = (size_t)c->ld;
+  const int R = m + 1; // rows 0..m
+  const int j0 = 1 + w * cpw;
+  const int nc = (j0 > n) ? 0 : ((j0 + cpw - 1 <= n) ? cpw : n - j0 + 1); // columns this workgroup owns
+  // LDS carve-up (doubles): tile[cpw][R] | beta[R] | colq[R] | blb[R] | bub[R] | bvar (ints)[R]
+  double *tile = smem;
+  double *beta = tile + (size_t)cpw * R;
+  double *colq = beta + R;
+  double *blb = colq + R;
+  double *bub = blb + R;
+  int *bvar = reinterpret_cast<int *>(bub + R);
+  // per-column state of the strip: lanes 0..nc-1 of wave 0 own one column each
+  const double tol_dj = c->tol_dj, tol_piv = c->tol_piv, sgn = c->sgn;
+  const int cur = c->curA & 1;
+  double *const pw_g = c->pw[cur];
+  int my_nvar = 0, my_nflag = MVX_NS;
+  double my_nlb = 0.0, my_nub = 0.0, my_w = 1.0;
+  if (TIDX < nc) {
+    my_nvar = c->nvar[j0 + TIDX];
+    my_nflag = c->nflag[j0 + TIDX];
+    my_nlb = c->nlb[j0 + TIDX];
+    my_nub = c->nub[j0 + TIDX];
+    my_w = pw_g[j0 + TIDX];
+  }
+  // load the strip (rows 0..m of the owned columns), column 0 and the row metadata
+  for (int i = TIDX; i < R; i += 256) {
+    const double *row = c->T + (size_t)i * ld;
+    for (int cc = 0; cc < nc; cc++) tile[(size_t)cc * R + i] = row[j0 + cc];
+    beta[i] = row[0];
+    blb[i] = i ? c->blb[i] : 0.0;
+    bub[i] = i ? c->bub[i] : 0.0;
+    bvar[i] = i ? c->bvar[i] : 0;
+  }
+  int it_cnt = c->it_cnt, n_flips = c->n_flips, stall = c->stall, budget = c->budget;
+  const int stall_limit = c->stall_limit;
+  __syncthreads();
+  bool ok = true;
+  int steps = 0;
+  unsigned it = 0; // iteration number; tags are it + 1
+  // first candidate of this strip
+  auto publish_candidate = [&](unsigned tag) {
+    // lanes 0..nc-1 price their column, wave 0 reduces, lane 0 publishes three tagged granules
+    if (TIDX < 64) {
+      Cand best{0.0, 0.0, 0, 0};
+      if (TIDX < nc) {
+        Cand x;
+        if (price_col(my_nflag, sgn * tile[(size_t)TIDX * R], tol_dj, j0 + TIDX, my_w, x)) best = x;
+      }
+      best = wave_best<0>(best);
+      if (TIDX == 0) {
+        const unsigned long long sc = d2u(best.k1), t = (unsigned long long)tag << 32;
+        const unsigned meta = ((unsigned)best.idx << 2) | (best.aux > 0 ? 1u : 0u) | (best.idx ? 2u : 0u);
+        unsigned long long *g = a.cand + ((size_t)(tag & 1) * a.nw + w) * 3;
+        st_agent(g + 0, t | (sc >> 32));
+        st_agent(g + 1, t | (sc & 0xffffffffull));
+        st_agent(g + 2, t | meta);
+      }
+    }
+  };
+  publish_candidate(1);
+  while (ok) {
+    const unsigned tag = it + 1;
+    // ---- gather every strip's candidate (wave 0), reduce to the entering column
+    if (TIDX < 64) {
+      Cand best{0.0, 0.0, 0, 0};
+      bool good = true;
+      for (int k = TIDX; k < a.nw; k += 64) {
+        const unsigned long long *g = a.cand + ((size_t)(tag & 1) * a.nw + k) * 3;
+        unsigned long long v0, v1, v2;
+        good = good && wait_tag(g + 0, tag, a.abort_flag, &v0) && wait_tag(g + 1, tag, a.abort_flag, &v1) && wait_tag(g + 2, tag, a.abort_flag, &v2);
+        if (!good) break;
+        const unsigned meta = (unsigned)v2;
+        if (meta & 2u) {
+          Cand x{u2d(((v0 & 0xffffffffull) << 32) | (v1 & 0xffffffffull)), 0.0, (int)(meta >> 2), (meta & 1u) ? 1 : -1};
+          if (cand_better<0>(x, best)) best = x;
+        }
+      }
+      const int allgood = __all(good ? 1 : 0);
+      best = wave_best<0>(best);
+      if (TIDX == 0) {
+        lds[16] = best;
+        s_ok = allgood;
+      }
+    }
+    __syncthreads();
+    if (!s_ok) {
+      ok = false;
+      break;
+    }
+    const Cand ent = lds[16];
+    const int q = ent.idx, sdir = ent.aux;
+    if (q == 0 || budget == 0 || stall >= stall_limit || steps >= a.max_steps) break; // the generic path takes over
+    const int owner = (q - 1) / cpw;
+    unsigned long long *msg = a.msg + (size_t)(tag & 1) * a.msg_stride;
+    if (owner == w) {
+      // ---- ratio test on the owned column, then the pivot message
+      const int cq = q - j0;
+      const double *col = tile + (size_t)cq * R;
+      Cand best{0.0, 0.0, 0, 0};
+      for (int i = 1 + TIDX; i < R; i += 256) {
+        Cand x;
+        if (ratio_row(col[i], sdir, beta[i], blb[i], bub[i], 0, tol_piv, i, x) && cand_better<1>(x, best)) best = x;
+      }
+      const Cand r = block_best<1>(best, lds);
+      // the entering column's own bounds / status live in lane cq of wave 0
+      const double lbq = __shfl(my_nlb, cq, 64), ubq = __shfl(my_nub, cq, 64), wq = __shfl(my_w, cq, 64);
+      const int fq = __shfl(my_nflag, cq, 64), vq = __shfl(my_nvar, cq, 64);
+      if (TIDX == 0) {
+        int kind = ST_PIVOT; // ST_PIVOT / ST_FLIP / ST_STOP
+        double delta = 0.0;
+        if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+          const double tf = ubq - lbq;
+          if (r.idx == 0 || tf <= r.k1) {
+            kind = ST_FLIP;
+            delta = (sdir > 0) ? tf : -tf;
+          }
+        }
+        if (kind == ST_PIVOT && r.idx == 0) kind = ST_STOP; // unbounded ray: the generic path reports it
+        const int p = r.idx, p_up = r.aux;
+        const double piv = p ? col[p] : 1.0;
+        const double bound = p ? (p_up ? bub[p] : blb[p]) : 0.0;
+        s_hdr[1] = (unsigned long long)kind;
+        s_hdr[2] = (unsigned long long)(unsigned)p | ((unsigned long long)(unsigned)p_up << 32);
+        s_hdr[3] = d2u(piv);
+        s_hdr[4] = d2u(bound);
+        s_hdr[5] = d2u(dev_nb_value(fq, lbq, ubq)); // xq
+        s_hdr[6] = d2u(lbq);
+        s_hdr[7] = d2u(ubq);
+        s_hdr[8] = d2u(delta);
+        s_hdr[9] = d2u(wq);
+        s_hdr[10] = (unsigned long long)(unsigned)vq;
+        s_hdr[11] = d2u(r.k1);
+        s_hdr[12] = (unsigned long long)(unsigned)((kind == ST_FLIP) ? ((sdir > 0) ? MVX_NU : MVX_NL) : (p ? dev_leave_flag(blb[p], bub[p], p_up) : 0));
+      }
+      __syncthreads();
+      for (int k = 1 + TIDX; k <= 12; k += 256) st_agent(msg + k, s_hdr[k]);
+      for (int i = TIDX; i < R; i += 256) {
+        const double v = col[i];
+        colq[i] = v;
+        st_agent(msg + PMSG_HDR + i, d2u(v));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the flag goes out
+      __syncthreads();
+      if (TIDX == 0) st_agent(msg, (unsigned long long)tag << 32);
+    } else {
+      if (TIDX == 0) {
+        unsigned long long v;
+        s_ok = wait_tag(msg, tag, a.abort_flag, &v) ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_ok) {
+        ok = false;
+        break;
+      }
+      for (int k = 1 + TIDX; k <= 12; k += 256) s_hdr[k] = ld_agent(msg + k);
+      for (int i = TIDX; i < R; i += 256) colq[i] = u2d(ld_agent(msg + PMSG_HDR + i));
+      __syncthreads();
+    }
+    // ---- apply the step to the strip
+    const int kind = (int)s_hdr[1];
+    if (kind == ST_STOP) break;
+    const int p = (int)(unsigned)(s_hdr[2] & 0xffffffffull);
+    const double piv = u2d(s_hdr[3]), bound = u2d(s_hdr[4]), xq = u2d(s_hdr[5]), ent_lb = u2d(s_hdr[6]), ent_ub = u2d(s_hdr[7]);
+    const double delta = u2d(s_hdr[8]), wq = u2d(s_hdr[9]), step_len = u2d(s_hdr[11]);
+    const int ent_var = (int)(unsigned)s_hdr[10], newflag = (int)(unsigned)s_hdr[12];
+    if (kind == ST_FLIP) {
+      // bound flip: only column 0 moves (rows 0..m), column q changes status
+      for (int i = TIDX; i < R; i += 256) beta[i] = fma(colq[i], delta, beta[i]);
+      if (owner == w && TIDX == q - j0) my_nflag = newflag;
+      n_flips++;
+      stall = 0;
+      __syncthreads();
+      it++;
+      publish_candidate(it + 1);
+      continue;
+    }
+    // pivot: scaled pivot-row entries of the strip, objective row, devex weights -> next candidate first
+    double s_own = 0.0; // lanes 0..nc-1: s_j of the owned column
+    const double s0 = xdiv(beta[p] - bound, piv);
+    if (TIDX < nc) {
+      const int j = j0 + TIDX;
+      double *col = tile + (size_t)TIDX * R;
+      s_own = xdiv(col[p], piv);
+      const double dq = colq[0];
+      col[0] = (j == q) ? xdiv(dq, piv) : fma(-dq, s_own, col[0]);
+      if (j == q) {
+        const double cc = xdiv(wq, piv * piv);
+        my_w = cc > 1.0 ? cc : 1.0;
+      } else {
+        const double cc = s_own * s_own * wq;
+        my_w = cc > my_w ? cc : my_w;
+      }
+    }
+    // bookkeeping of the swap: the leaving variable takes column q, the entering one takes row p
+    const int lv_var = bvar[p];
+    const double lv_lb = blb[p], lv_ub = bub[p];
+    if (owner == w && TIDX == q - j0) {
+      my_nvar = lv_var;
+      my_nlb = lv_lb;
+      my_nub = lv_ub;
+      my_nflag = newflag;
+    }
+    __syncthreads(); // everyone has read row p's old metadata and beta[p]
+    it++;
+    publish_candidate(it + 1);
+    // bulk update of the strip (rows 1..m; row 0 is done), column 0, metadata of row p
+    {
+      // s_j per owned column, for every lane: from the (still old) row p entries
+      double sc[PERSIST_MAX_CPW];
+      for (int cc = 0; cc < nc; cc++) sc[cc] = xdiv(tile[(size_t)cc * R + p], piv);
+      __syncthreads(); // row p is read by all before anyone overwrites it
+      for (int i = 1 + TIDX; i < R; i += 256) {
+        const double ci = colq[i];
+        if (i == p) {
+          for (int cc = 0; cc < nc; cc++) tile[(size_t)cc * R + i] = (j0 + cc == q) ? xdiv(1.0, piv) : -sc[cc];
+          beta[i] = xq - s0;
+        } else {
+          for (int cc = 0; cc < nc; cc++) {
+            double *e = tile + (size_t)cc * R + i;
+            *e = (j0 + cc == q) ? xdiv(ci, piv) : fma(-ci, sc[cc], *e);
+          }
+          beta[i] = fma(-ci, s0, beta[i]);
+        }
+      }
+      if (TIDX == 0) {
+        beta[0] = fma(-colq[0], s0, beta[0]);
+        bvar[p] = ent_var;
+        blb[p] = ent_lb;
+        bub[p] = ent_ub;
+      }
+    }
+    it_cnt++;
+    if (budget > 0) budget--;
+    stall = (step_len <= DEGEN_TOL) ? stall + 1 : 0;
+    steps++;
+    __syncthreads();
+  }
+  if (!ok && TIDX == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- write the strip, column 0 and the metadata back (the tableau is consistent after any whole step)
+  __syncthreads();
+  for (int i = TIDX; i < R; i += 256) {
+    double *row = c->T + (size_t)i * ld;
+    for (int cc = 0; cc < nc; cc++) row[j0 + cc] = tile[(size_t)cc * R + i];
+    if (w == 0) {
+      row[0] = beta[i];
+      if (i) {
+        c->bvar[i] = bvar[i];
+        c->blb[i] = blb[i];
+        c->bub[i] = bub[i];
+      }
+    }
+  }
+  if (TIDX < nc) {
+    c->nvar[j0 + TIDX] = my_nvar;
+    c->nflag[j0 + TIDX] = my_nflag;
+    c->nlb[j0 + TIDX] = my_nlb;
+    c->nub[j0 + TIDX] = my_nub;
+    pw_g[j0 + TIDX] = my_w;
+  }
+  if (w == 0 && TIDX == 0) {
+    c->it_cnt = it_cnt;
+    c->n_flips = n_flips;
+    c->stall = stall;
+    c->budget = budget;
+    c->step = ST_NONE;
+  }
+}
+
 // ======================================================================= GMI cuts on the device
 // generateCut3 (/root/reference/gmi.cpp:11-117) and its repaired variant, for `count` basic integer columns of one
 // solved node at once.  k_gmi_work turns the tableau row of each column into the coefficient vector `work` by
@@ -1428,6 +1804,28 @@ __global__ __launch_bounds__(256) void k_gmi_backsub(GmiArgs a) {
   }
 }
 
+// LDS bytes of one k_persist workgroup: the strip, column 0, the pivot column, row bounds (f64) and basic variables (i32)
+size_t persist_lds_bytes(int m, int cpw) { return ((size_t)(m + 1) * (size_t)(cpw + 4)) * 8 + (size_t)(m + 1) * 4 + 64; }
+int persist_max_cpw() { return PERSIST_MAX_CPW; }
+int persist_msg_words(int m_cap) { return PMSG_HDR + m_cap + 1; }
+int launch_persist(Ctl *d_ctl, unsigned long long *cand, unsigned long long *msg, int *abort_flag, int m, int cpw, int nw, int msg_stride,
+                   int max_steps, hipStream_t s) {
+  static size_t attr_bytes = 0;
+  const size_t lds = persist_lds_bytes(m, cpw);
+  if (lds > attr_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    attr_bytes = lds;
+  }
+  PersistArgs a;
+  a.ctl = d_ctl; a.cand = cand; a.msg = msg; a.abort_flag = abort_flag;
+  a.cpw = cpw; a.nw = nw; a.msg_stride = msg_stride; a.max_steps = max_steps;
+  hipLaunchKernelGGL(k_persist, dim3((unsigned)nw), dim3(256), lds, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 void launch_gmi(const GmiArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_gmi_work, dim3((unsigned)a.count), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_gmi_backsub, dim3((unsigned)((a.n + 255) / 256), (unsigned)((a.count + GMI_CT - 1) / GMI_CT)), dim3(256), 0, s, a);
@@ -1476,7 +1874,13 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
 #undef FB_CASE
   std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
 }
-void launch_select(Ctl *d_ctl, hipStream_t s, int slots) { hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl); }
+void launch_select(Ctl *d_ctl, hipStream_t s, int slots) {
+  BatchQueue q{};
+  hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl, q);
+}
+void launch_select_queue(Ctl *d_ctl, const BatchQueue &q, hipStream_t s, int slots) {
+  hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl, q);
+}
 void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
   const int pairs = (n + 2) / 2;
   const long tiles = (pairs + 255) / 256;

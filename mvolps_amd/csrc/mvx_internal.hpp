@@ -25,7 +25,7 @@ constexpr int ROW_SLACK = 64;     // spare tableau rows per handle for cut appen
 constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this counts as degenerate (oracle: DEGEN_TOL)
 constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
-constexpr int MAX_EDITS = 4;      // pending bound edits a control block carries (more are flushed by launches)
+constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
 
 // state-machine phases (device-driven; mirrors orc_simplex's round loop)
@@ -95,6 +95,22 @@ struct Ctl {
   // launch per edit
   int n_edits, edit_row[MAX_EDITS];
   double edit_lb[MAX_EDITS], edit_ub[MAX_EDITS];
+  int job; // batched solve: which job of the queue this slot is working on (-1: none)
+};
+
+// Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots
+// of the launch pull them -- a slot whose solve has ended exports its mirrors into the job's staging area and takes the
+// next job in the very launch that finds it idle, instead of idling until the host's next synchronisation point.
+struct SlotScratch { // per-slot scratch the pulled control block is pointed at
+  double *colq, *srow, *olb, *oub, *dw, *pw;
+};
+struct BatchQueue {
+  const Ctl *jobs;
+  const SlotScratch *scratch;
+  int *counters; // [0] next job to hand out, [1] jobs finished and exported
+  unsigned char *stage;
+  size_t stage_stride;
+  int count;
 };
 
 // one launch of k_copy_many: up to COPY_BATCH byte ranges (16-byte aligned, sizes multiples of 16)

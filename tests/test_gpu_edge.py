@@ -107,3 +107,31 @@ def test_columns_added_after_a_solve(gpu, orc):
     assert np.array_equal(g.tableau(), o.tableau())
     for x, y in zip(g.basis(), o.basis()):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n_edits", [3, 8, 9, 13])
+def test_many_bound_edits_on_a_fresh_clone(gpu, orc, n_edits):
+    """Bound edits of basic variables wait on the handle and ride in the next solve's control block (MAX_EDITS of
+    them; more are flushed by launches), and a clone is only recorded until the next device call: edits made on a
+    clone whose copy has not been launched yet must still land AFTER the copy (the flush launches the copy first)."""
+    A, b, c, U = synth.dense_ilp(40, 80, 9, 3)
+    g, o = lpgen.load_ilp(gpu, A, b, c, U), lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    x = o.col_prim()
+    stat = o.col_stat()
+    basic = [j + 1 for j in range(80) if stat[j] == capi.BS][:n_edits]
+    assert len(basic) == n_edits
+    kids = []
+    for P in (g, o):
+        Q = P.copy()  # recorded, not yet launched, on the device side
+        for j in basic:
+            P.api.set_col_bnds(Q.h, j, capi.DB, 0.0, float(np.floor(x[j - 1])))
+        R = Q.copy()  # the clone of a handle with pending edits inherits them
+        Q.simplex()
+        R.simplex()
+        kids.append((Q, R))
+    (gq, gr), (oq, orr) = kids
+    for a_, b_ in ((gq, oq), (gr, orr)):
+        assert a_.status == b_.status and a_.it_cnt == b_.it_cnt
+        assert np.array_equal(a_.tableau(), b_.tableau())
