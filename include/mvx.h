@@ -182,6 +182,17 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf);
 /* streamed-update tuning (row-block depth 8/16/32, batched-load hot loop, non-temporal access);
    for measurement sweeps -- results are identical for every setting */
 void mvx_set_tuning(int tr, int hot, int nt);
+/* Tableau refresh.  A dense Gauss-Jordan tableau carries the rounding of every pivot it has been through (GLPK
+   refactorises its basis behind glp_simplex, bs.cpp:117).  A solve that ends OPTIMAL on a handle with at least
+   `check_every` pivots since the last look (default 1024; clones inherit the count) computes the residual of the row
+   equations, max_i |sum_j a_ij x_j - x_Ri| / (1 + |x_Ri|) (mvx_row_residual); above `tol` (default 1e-9) the tableau
+   is rebuilt from the model for the same basis -- slack tableau with the non-basic variables on their bounds, then
+   the basic structural variables pivoted back in by ascending variable number, each on the row of largest |entry|
+   among the rows whose auxiliary has to leave -- and the simplex carries on.  Same rule, same arithmetic, in the
+   CPU oracle.  mvx_get_refresh_cnt: refreshes on this handle's lineage */
+void mvx_set_refresh(int check_every, double tol);
+int mvx_get_refresh_cnt(const mvx_prob *P);
+double mvx_row_residual(const mvx_prob *P);
 /* resident-tableau path of primal phase 2 (cache-resident sizes: one launch keeps the tableau in LDS for the whole
    run of pivots): 1 on, 0 off, -1 back to the default (on unless the environment has MVX_PERSIST=0).  Results are
    identical either way.  mvx_persist_stats: launches made / launches that aborted and were redone by the two-kernel path */

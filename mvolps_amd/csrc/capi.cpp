@@ -60,6 +60,8 @@ static void reset_model(mvx_prob *P) {
   P->valid = false;
   P->status = MVX_UNDEF;
   P->it_cnt = 0;
+  P->piv_since_check = 0;
+  P->refresh_cnt = 0;
   P->bland_cnt = 0;
   P->pert_cnt = 0;
   P->last_ms = 0.0;
@@ -101,6 +103,8 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   dst->ctype = src->ctype; dst->clb = src->clb; dst->cub = src->cub;
   dst->status = src->status; dst->it_cnt = src->it_cnt; dst->bland_cnt = src->bland_cnt; dst->pert_cnt = src->pert_cnt; dst->last_ms = 0.0;
   dst->hint_dual = src->hint_dual;
+  dst->piv_since_check = src->piv_since_check;
+  dst->refresh_cnt = src->refresh_cnt;
   dst->pending = src->pending;
   dst->dmat = src->dmat;
   std::memcpy(dst->last_tol, src->last_tol, sizeof(dst->last_tol));
@@ -444,6 +448,9 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
 }
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
 void mvx_set_stall_limit(int limit) { mvx::set_stall_limit(limit); }
+void mvx_set_refresh(int check_every, double tol) { mvx::set_refresh(check_every, tol); }
+int mvx_get_refresh_cnt(const mvx_prob *P) { return P->refresh_cnt; }
+double mvx_row_residual(const mvx_prob *P) { return mvx::row_residual(P); }
 void mvx_set_persist(int mode) { mvx::set_persist(mode); }
 void mvx_persist_stats(long long *launches, long long *aborts) { mvx::persist_stats(launches, aborts); }
 void mvx_set_batch_slots(int slots) { mvx::set_batch_slots(slots); }

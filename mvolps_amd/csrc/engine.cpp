@@ -59,6 +59,7 @@ void launch_p1_fix(Ctl *, int n, hipStream_t);
 void launch_scatter_ctl(Ctl *dst, const Ctl *src, const int *idx, int count, hipStream_t);
 void launch_copy_many(const CopyBatch &b, hipStream_t);
 void launch_gmi(const GmiArgs &a, hipStream_t);
+void launch_refresh_select(Ctl *, const int *tflag, int var, hipStream_t);
 size_t persist_lds_bytes(int m, int cpw);
 int persist_max_cpw();
 int persist_msg_words(int m_cap);
@@ -89,6 +90,7 @@ struct SolveCtx {
   double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
   double *d_dw = nullptr; // dual devex weights by row
   int *d_p1list = nullptr; // phase 1: rows whose infeasibility sign changed
+  int *d_tflag = nullptr;  // tableau refresh: target non-basic status by variable number
   double *d_pw[2] = {nullptr, nullptr}; // primal devex weights by column, two sets (fused path ping-pong)
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
@@ -254,6 +256,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_dw = carve((size_t)(mc + 1) * 8);
   size_t o_p1l = carve((size_t)(mc + 2) * 4);
   size_t o_pw0 = carve((size_t)l * 8), o_pw1 = carve((size_t)l * 8);
+  size_t o_tf = carve((size_t)(mc + l + 1) * 4);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -277,6 +280,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_p1list = (int *)(b + o_p1l);
   sc.d_pw[0] = (double *)(b + o_pw0);
   sc.d_pw[1] = (double *)(b + o_pw1);
+  sc.d_tflag = (int *)(b + o_tf);
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
@@ -592,7 +596,7 @@ void refresh_solution(const mvx_prob *Pc) {
 
 // ---------------------------------------------------------------------- tableau build
 // false: the device is out of memory (mvx_last_error() reads MVX_ENOMEM); the handle stays without a tableau
-static bool build_slack_tableau(mvx_prob *P) {
+static bool build_slack_tableau(mvx_prob *P, const int *sflag = nullptr) { // sflag: non-basic status per structural column (refresh)
   Context &c = ctx();
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
@@ -612,7 +616,7 @@ static bool build_slack_tableau(mvx_prob *P) {
   bool any_x = false;
   for (int j = 1; j <= n; j++) {
     P->nvar[j] = m + j;
-    P->nflag[j] = std_flag(P->ctype[j]);
+    P->nflag[j] = sflag ? sflag[j] : std_flag(P->ctype[j]);
     nlb[j] = P->clb[j];
     nub[j] = P->cub[j];
     xn[j] = nb_value(P->nflag[j], nlb[j], nub[j]);
@@ -859,7 +863,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
         HIPCHECK(hipMemcpyAsync(sc.d_pctl, sc.d_ctl, sizeof(Ctl), hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw, sc.d_pw[0], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw + P->ld, sc.d_pw[1], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
-        HIPCHECK(hipMemsetAsync(sc.d_pcand, 0, (size_t)2 * pl.nw * 3 * 8, sc.stream));
+        HIPCHECK(hipMemsetAsync(sc.d_pcand, 0, (size_t)2 * pl.nw * 4 * 8, sc.stream));
         HIPCHECK(hipMemsetAsync(sc.d_pmsg, 0, (size_t)2 * sc.p_msg_words * 8, sc.stream));
         const int steps = 1 << 24; // the pivot limit is the control block's `budget`, which the kernel counts down
         if (launch_persist(sc.d_ctl, sc.d_pcand, sc.d_pmsg, sc.d_pabort, P->m, pl.cpw, pl.nw, sc.p_msg_words, steps, sc.stream) == 0) {
@@ -1047,7 +1051,7 @@ static bool job_prepare(SolveJob &J, mvx_prob *P, const mvx_smcp *parm) {
   return true;
 }
 
-static int engine_simplex_on(mvx_prob *P, const mvx_smcp *parm, bool aux) {
+static int solve_once(mvx_prob *P, const mvx_smcp *parm, bool aux) {
   SolveJob J;
   if (!job_prepare(J, P, parm)) return J.rc;
   Context &c = ctx();
@@ -1067,6 +1071,86 @@ static int engine_simplex_on(mvx_prob *P, const mvx_smcp *parm, bool aux) {
     if (job_collect(c, J)) break;
   }
   return J.rc;
+}
+
+// ---- tableau refresh (same rule and arithmetic as the oracle's refresh_tableau / orc_row_residual)
+static int g_check_every = 1024;
+static double g_refresh_tol = 1e-9;
+void set_refresh(int check_every, double tol) {
+  g_check_every = check_every > 0 ? check_every : 1024;
+  g_refresh_tol = tol >= 0.0 ? tol : 1e-9;
+}
+
+double row_residual(const mvx_prob *P) {
+  if (!P->valid) return 0.0;
+  refresh_solution(P);
+  const int m = P->m, n = P->n;
+  auto value = [&](int k) {
+    const int pos = P->pos[(size_t)k];
+    if (pos > 0) return P->beta[(size_t)pos];
+    double lb, ub;
+    var_bounds(P, k, &lb, &ub);
+    return nb_value(P->nflag[(size_t)-pos], lb, ub);
+  };
+  std::vector<double> x((size_t)n + 1, 0.0);
+  for (int j = 1; j <= n; j++) x[(size_t)j] = value(m + j);
+  double worst = 0.0;
+  for (int i = 1; i <= m; i++) {
+    const double *a = P->A[(size_t)i]->data();
+    double acc = 0.0;
+    for (int j = 1; j <= n; j++) acc = acc + a[j] * x[(size_t)j];
+    const double xr = value(i);
+    const double r = std::fabs(acc - xr) / (1.0 + std::fabs(xr));
+    if (r > worst) worst = r;
+  }
+  return worst;
+}
+
+static bool refresh_tableau(mvx_prob *P) {
+  Context &c = ctx();
+  MAIN_LOCK(c);
+  flush_copies(c);
+  SolveCtx &sc = c.main;
+  const int m = P->m, n = P->n;
+  std::vector<int> tflag((size_t)m + n + 1, 0), sflag((size_t)n + 1, 0);
+  for (int j = 1; j <= n; j++) tflag[(size_t)P->nvar[(size_t)j]] = P->nflag[(size_t)j];
+  for (int j = 1; j <= n; j++) sflag[(size_t)j] = tflag[(size_t)m + j] ? tflag[(size_t)m + j] : std_flag(P->ctype[(size_t)j]);
+  const int status = P->status;
+  if (!build_slack_tableau(P, sflag.data())) return false;
+  ensure_scratch(sc, P->m_cap, P->ld);
+  HIPCHECK(hipMemcpyAsync(sc.d_tflag, tflag.data(), tflag.size() * 4, hipMemcpyHostToDevice, sc.stream));
+  fill_ctl(sc, P, sc.h_ctl);
+  upload_ctl(sc);
+  for (int k = m + 1; k <= m + n; k++) {
+    if (tflag[(size_t)k]) continue; // non-basic in the target basis
+    launch_refresh_select(sc.d_ctl, sc.d_tflag, k, sc.stream);
+    launch_update(sc.d_ctl, m, n, sc.stream);
+  }
+  launch_export(sc.d_ctl, sc.d_stage, m, n, 1, sc.stream);
+  pull_stage(sc, P, true); // synchronises: tflag / the control block may go out of scope
+  P->status = status;
+  P->refresh_cnt++;
+  return true;
+}
+
+// the counter / residual / refresh step that follows every solve (oracle: orc_simplex)
+static int after_solve(mvx_prob *P, const mvx_smcp *parm, int rc, int pivots) {
+  P->piv_since_check += pivots;
+  if (rc == 0 && P->status == MVX_OPT && P->piv_since_check >= g_check_every) {
+    P->piv_since_check = 0;
+    if (row_residual(P) > g_refresh_tol && refresh_tableau(P)) {
+      const int before = P->it_cnt;
+      rc = solve_once(P, parm, true); // the pivot limit of the call, if any, applies to this leg afresh
+      P->piv_since_check += P->it_cnt - before;
+    }
+  }
+  return rc;
+}
+
+static int engine_simplex_on(mvx_prob *P, const mvx_smcp *parm, bool aux) {
+  const int before = P->it_cnt;
+  const int rc = solve_once(P, parm, aux);
+  return after_solve(P, parm, rc, P->it_cnt - before);
 }
 
 int engine_simplex(mvx_prob *P, const mvx_smcp *parm) { return engine_simplex_on(P, parm, false); }
@@ -1173,11 +1257,12 @@ static void batch_fill_job(Ctl *h, mvx_prob *P, const mvx_smcp &parm) {
 }
 
 // mirrors + status of a finished job; layout inside the staging area follows the handle's own m_cap / ld
-static int batch_finish_job(BatchCtx &bc, int j, mvx_prob *P, int *done_code) {
+static int batch_finish_job(BatchCtx &bc, int j, mvx_prob *P, int *done_code, int *pivots) {
   const unsigned char *s = bc.h_stage + (size_t)j * bc.stage_stride;
   Ctl snap;
   std::memcpy(&snap, s, sizeof(Ctl));
   *done_code = snap.done;
+  *pivots = snap.it_cnt;
   P->it_cnt += snap.it_cnt;
   P->bland_cnt += snap.n_bland;
   P->pert_cnt += snap.n_pert;
@@ -1284,10 +1369,15 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   HIPCHECK(hipStreamSynchronize(bc.stream));
   for (int j = 0; j < njobs; j++) {
     const int i = pending[(size_t)j];
-    int code = 0;
-    const int rc = batch_finish_job(bc, j, probs[i], &code);
-    if (code == D_NEED_PHASE1) fallback.push_back(i);
-    else if (rcs) rcs[i] = rc;
+    int code = 0, piv = 0;
+    int rc = batch_finish_job(bc, j, probs[i], &code, &piv);
+    if (code == D_NEED_PHASE1) {
+      fallback.push_back(i);
+      probs[i]->piv_since_check += piv; // the single-handle leg below adds its own and applies the refresh rule
+    } else {
+      rc = after_solve(probs[i], &parm, rc, piv); // residual look / tableau refresh, as after any solve
+      if (rcs) rcs[i] = rc;
+    }
   }
   for (int i : fallback) {
     // the batch left this handle untouched apart from zero or more completed pivots
@@ -1710,7 +1800,7 @@ int engine_pack(const mvx_prob *P, int m_base, void *dev_buf) {
   unsigned char *b = host.data();
   PackHdr h{};
   h.magic = PACK_MAGIC; h.m = m; h.n = n; h.ld = P->ld; h.m_cap = P->m_cap; h.status = P->status;
-  h.it_cnt = P->it_cnt; h.valid = P->valid; h.hint_dual = P->hint_dual; h.host_bytes = (long long)hb; h.m_base = m_base;
+  h.it_cnt = P->it_cnt; h.valid = P->valid; h.hint_dual = P->hint_dual; h.host_bytes = (long long)hb; h.m_base = m_base; h.reserved = P->piv_since_check;
   std::memcpy(h.last_tol, P->last_tol, sizeof(h.last_tol));
   std::memcpy(b, &h, sizeof(h));
   b += sizeof(h);
@@ -1793,6 +1883,7 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   dst->status = (int)h.status;
   dst->it_cnt = (int)h.it_cnt;
   dst->hint_dual = h.hint_dual != 0;
+  dst->piv_since_check = (int)h.reserved;
   std::memcpy(dst->last_tol, h.last_tol, sizeof(dst->last_tol));
   dst->sol_fresh = false;
   release_device(dst);

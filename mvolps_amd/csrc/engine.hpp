@@ -37,6 +37,8 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf);
 void tuning(int tr, int hot, int nt);
 void set_stall_limit(int limit);
 void set_persist(int mode);
+void set_refresh(int check_every, double tol);
+double row_residual(const mvx_prob *P);
 void persist_stats(long long *launches, long long *aborts);
 void set_batch_slots(int k);
 void profile_enable(int on);

@@ -771,6 +771,62 @@ __global__ __launch_bounds__(1024) void k_p1_select(Ctl *c) {
   }
 }
 
+// ---------------------------------------------------------------------------- k_refresh_select
+// Tableau refresh (engine.cpp refresh_tableau; oracle: refresh_tableau): structural variable `var` has to be basic.
+// Its column is wherever the slack tableau / the pivots so far left it; it enters on the row of largest |entry|
+// (lowest row on ties) among the rows whose basic auxiliary is non-basic in the target basis, which leaves to the
+// bound `tflag` names.  Prepares the pivot for k_update exactly as k_select does.
+__global__ __launch_bounds__(1024) void k_refresh_select(Ctl *c, const int *tflag, int var) {
+  __shared__ Cand lds[17];
+  __shared__ int s_q;
+  const KC k = load_kc(c);
+  if (TIDX == 0) {
+    s_q = 0;
+    c->step = ST_NONE;
+  }
+  __syncthreads();
+  for (int j = 1 + TIDX; j <= k.n; j += (int)blockDim.x)
+    if (k.nvar[j] == var) s_q = j;
+  __syncthreads();
+  const int q = s_q;
+  if (q == 0) return;
+  const size_t ld = (size_t)k.ld;
+  Cand best{0.0, 0.0, 0, 0};
+  for (int i = TIDX; i <= k.m; i += (int)blockDim.x) {
+    const double a = k.T[(size_t)i * ld + q];
+    k.colq[i] = a;
+    if (i == 0) continue;
+    const int v = k.bvar[i];
+    if (v > k.m || tflag[v] == 0) continue;
+    const double mag = fabs(a);
+    Cand x{mag, 0.0, i, tflag[v]};
+    if (mag > 0.0 && cand_better<0>(x, best)) best = x;
+  }
+  best = block_best<0>(best, lds);
+  if (best.idx == 0) return;
+  const int p = best.idx, tf = best.aux;
+  const double *rowp = k.T + (size_t)p * ld;
+  const double piv = rowp[q];
+  const double bound = (tf == MVX_NU) ? k.bub[p] : (tf == MVX_NF ? 0.0 : k.blb[p]);
+  for (int j = TIDX; j <= k.n; j += (int)blockDim.x) {
+    const double v = rowp[j];
+    k.srow[j] = (j == 0) ? xdiv(v - bound, piv) : xdiv(v, piv);
+  }
+  if (TIDX == 0) {
+    c->step = ST_PIVOT;
+    c->p = p;
+    c->q = q;
+    c->p_up = (tf == MVX_NU);
+    c->piv = piv;
+    c->bound = bound;
+    c->xq = dev_nb_value(k.nflag[q], k.nlb[q], k.nub[q]);
+    c->leave_flag = tf;
+  }
+}
+void launch_refresh_select(Ctl *d_ctl, const int *tflag, int var, hipStream_t s) {
+  hipLaunchKernelGGL(k_refresh_select, dim3(1), dim3(1024), 0, s, d_ctl, tflag, var);
+}
+
 // ---------------------------------------------------------------------------- k_update
 template <int NT>
 __device__ __forceinline__ double2 ld2(const double2 *p) {
@@ -1326,13 +1382,13 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 // a shared abort flag, so the grid always drains (the host then falls back on k_fa / k_fb for good).
 struct PersistArgs {
   Ctl *ctl;
-  unsigned long long *cand; // [2][nw][3] tagged candidate granules
-  unsigned long long *msg;  // [2][PMSG_HDR + m_cap + 1] pivot message: flag, header, column q
+  unsigned long long *cand; // [2][nw][2] tagged candidate granules
+  unsigned long long *msg;  // [2][2 * (PMSG_HDR + m_cap + 1)] pivot message: header + column q, two tagged granules per word
   int *abort_flag;
   int cpw, nw, msg_stride, max_steps;
 };
-constexpr int PMSG_HDR = 16; // u64 words in front of the column in a pivot message (word 0 = flag)
-constexpr int PERSIST_SPIN = 1 << 21;
+constexpr int PMSG_HDR = 16; // 64-bit words in front of the column in a pivot message
+constexpr int PERSIST_SPIN = 1 << 20;
 constexpr int PERSIST_MAX_CPW = 16;
 
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
@@ -1343,21 +1399,47 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
 }
 __device__ __forceinline__ unsigned long long d2u(double x) { return (unsigned long long)__double_as_longlong(x); }
 __device__ __forceinline__ double u2d(unsigned long long x) { return __longlong_as_double((long long)x); }
+// a 64-bit word as two self-validating granules {tag : 32 | half : 32}: the reader needs no flag and no fence,
+// a granule is one naturally aligned 8-byte store (MI355X_MICROARCH.md: data-tagged granules)
+__device__ __forceinline__ void put_word(unsigned long long *g, unsigned long long v, unsigned tag) {
+  const unsigned long long t = (unsigned long long)tag << 32;
+  st_agent(g, t | (v >> 32));
+  st_agent(g + 1, t | (v & 0xffffffffull));
+}
+__device__ __forceinline__ bool persist_aborted(const int *abort_flag) {
+  return __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
-// one lane waits until *p carries `want` in its high word (bounded); false = abort
-__device__ __forceinline__ bool wait_tag(const unsigned long long *p, unsigned want, const int *abort_flag, unsigned long long *out) {
-  for (int spin = 0; spin < PERSIST_SPIN; spin++) {
-    const unsigned long long v = ld_agent(p);
-    if ((unsigned)(v >> 32) == want) {
-      *out = v;
-      return true;
-    }
-    if ((spin & 255) == 255) {
-      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-      __builtin_amdgcn_s_sleep(2);
+// NW words (2 granules each) at g + 2 * (first + k * stride), k = 0..NW-1, all loads of a sweep in flight together;
+// re-reads only what has not arrived.  false = gave up (abort)
+template <int NW>
+__device__ __forceinline__ bool get_words(const unsigned long long *g, int first, int stride, int count, unsigned tag, const int *abort_flag,
+                                          unsigned long long (&out)[NW]) {
+  unsigned pending = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++)
+    if (first + k * stride < count) pending |= 1u << k;
+  for (int spin = 0; pending && spin < PERSIST_SPIN; spin++) {
+    unsigned long long a[NW], b[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+      if (pending & (1u << k)) {
+        const unsigned long long *p = g + 2 * (size_t)(first + k * stride);
+        a[k] = ld_agent(p);
+        b[k] = ld_agent(p + 1);
+      }
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+      if ((pending & (1u << k)) && (unsigned)(a[k] >> 32) == tag && (unsigned)(b[k] >> 32) == tag) {
+        out[k] = (a[k] << 32) | (b[k] & 0xffffffffull);
+        pending &= ~(1u << k);
+      }
+    if (pending && (spin & 63) == 63) {
+      if (persist_aborted(abort_flag)) return false;
+      __builtin_amdgcn_s_sleep(1);
     }
   }
-  return false;
+  return pending == 0;
 }
 
 __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
@@ -1367,7 +1449,7 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
   __shared__ int s_ok;
   Ctl *c = a.ctl;
   if (c->done != D_RUN || c->phase != PH_PRIMAL2 || c->stall >= c->stall_limit || c->budget == 0 || c->perturbed) return;
-  if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  if (persist_aborted(a.abort_flag)) return;
   const int m = c->m, n = c->n, cpw = a.cpw, w = (int)blockIdx.x;
   const size_t ld = (size_t)c->ld;
   const int R = m + 1; // rows 0..m
@@ -1408,9 +1490,8 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
   bool ok = true;
   int steps = 0;
   unsigned it = 0; // iteration number; tags are it + 1
-  // first candidate of this strip
   auto publish_candidate = [&](unsigned tag) {
-    // lanes 0..nc-1 price their column, wave 0 reduces, lane 0 publishes three tagged granules
+    // lanes 0..nc-1 price their column, wave 0 reduces, lane 0 publishes: {score} and {column, direction}
     if (TIDX < 64) {
       Cand best{0.0, 0.0, 0, 0};
       if (TIDX < nc) {
@@ -1419,32 +1500,38 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
       }
       best = wave_best<0>(best);
       if (TIDX == 0) {
-        const unsigned long long sc = d2u(best.k1), t = (unsigned long long)tag << 32;
-        const unsigned meta = ((unsigned)best.idx << 2) | (best.aux > 0 ? 1u : 0u) | (best.idx ? 2u : 0u);
-        unsigned long long *g = a.cand + ((size_t)(tag & 1) * a.nw + w) * 3;
-        st_agent(g + 0, t | (sc >> 32));
-        st_agent(g + 1, t | (sc & 0xffffffffull));
-        st_agent(g + 2, t | meta);
+        unsigned long long *g = a.cand + ((size_t)(tag & 1) * a.nw + w) * 4;
+        put_word(g, d2u(best.k1), tag);
+        put_word(g + 2, ((unsigned long long)(unsigned)best.idx << 1) | (best.aux > 0 ? 1ull : 0ull), tag);
       }
     }
   };
   publish_candidate(1);
   while (ok) {
     const unsigned tag = it + 1;
-    // ---- gather every strip's candidate (wave 0), reduce to the entering column
+    // ---- gather every strip's candidate (wave 0: up to four strips per lane, all loads in flight), reduce
     if (TIDX < 64) {
-      Cand best{0.0, 0.0, 0, 0};
+      const unsigned long long *g = a.cand + (size_t)(tag & 1) * a.nw * 4;
+      unsigned long long wd[8];
+      // words 2k (score) and 2k+1 (column) of strip TIDX + 64 * (k / ...): laid out as [strip][2 words]
       bool good = true;
-      for (int k = TIDX; k < a.nw; k += 64) {
-        const unsigned long long *g = a.cand + ((size_t)(tag & 1) * a.nw + k) * 3;
-        unsigned long long v0, v1, v2;
-        good = good && wait_tag(g + 0, tag, a.abort_flag, &v0) && wait_tag(g + 1, tag, a.abort_flag, &v1) && wait_tag(g + 2, tag, a.abort_flag, &v2);
-        if (!good) break;
-        const unsigned meta = (unsigned)v2;
-        if (meta & 2u) {
-          Cand x{u2d(((v0 & 0xffffffffull) << 32) | (v1 & 0xffffffffull)), 0.0, (int)(meta >> 2), (meta & 1u) ? 1 : -1};
-          if (cand_better<0>(x, best)) best = x;
+      Cand best{0.0, 0.0, 0, 0};
+      {
+        unsigned long long sc[4], mt[4];
+        good = get_words<4>(g, 2 * TIDX, 128, 2 * a.nw, tag, a.abort_flag, sc);
+        good = good && get_words<4>(g, 2 * TIDX + 1, 128, 2 * a.nw, tag, a.abort_flag, mt);
+        if (good) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (TIDX + 64 * k >= a.nw) continue;
+            const int idx = (int)(mt[k] >> 1);
+            if (idx) {
+              Cand x{u2d(sc[k]), 0.0, idx, (mt[k] & 1ull) ? 1 : -1};
+              if (cand_better<0>(x, best)) best = x;
+            }
+          }
         }
+        (void)wd;
       }
       const int allgood = __all(good ? 1 : 0);
       best = wave_best<0>(best);
@@ -1463,8 +1550,9 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
     if (q == 0 || budget == 0 || stall >= stall_limit || steps >= a.max_steps) break; // the generic path takes over
     const int owner = (q - 1) / cpw;
     unsigned long long *msg = a.msg + (size_t)(tag & 1) * a.msg_stride;
+    __syncthreads(); // lds[16] / s_ok are reused below
     if (owner == w) {
-      // ---- ratio test on the owned column, then the pivot message
+      // ---- ratio test on the owned column, then the pivot message (every word self-tagged: no flag)
       const int cq = q - j0;
       const double *col = tile + (size_t)cq * R;
       Cand best{0.0, 0.0, 0, 0};
@@ -1504,28 +1592,34 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
         s_hdr[12] = (unsigned long long)(unsigned)((kind == ST_FLIP) ? ((sdir > 0) ? MVX_NU : MVX_NL) : (p ? dev_leave_flag(blb[p], bub[p], p_up) : 0));
       }
       __syncthreads();
-      for (int k = 1 + TIDX; k <= 12; k += 256) st_agent(msg + k, s_hdr[k]);
+      if (TIDX >= 1 && TIDX <= 12) put_word(msg + 2 * TIDX, s_hdr[TIDX], tag);
       for (int i = TIDX; i < R; i += 256) {
         const double v = col[i];
         colq[i] = v;
-        st_agent(msg + PMSG_HDR + i, d2u(v));
+        put_word(msg + 2 * (size_t)(PMSG_HDR + i), d2u(v), tag);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the flag goes out
       __syncthreads();
-      if (TIDX == 0) st_agent(msg, (unsigned long long)tag << 32);
     } else {
-      if (TIDX == 0) {
-        unsigned long long v;
-        s_ok = wait_tag(msg, tag, a.abort_flag, &v) ? 1 : 0;
+      // header (lanes 1..12) and column q (every lane: rows TIDX, TIDX + 256, ...), one sweep of loads each
+      bool good = true;
+      if (TIDX >= 1 && TIDX <= 12) {
+        unsigned long long v[1];
+        good = get_words<1>(msg, TIDX, 1, PMSG_HDR, tag, a.abort_flag, v);
+        if (good) s_hdr[TIDX] = v[0];
       }
-      __syncthreads();
-      if (!s_ok) {
+      for (int i0 = 0; i0 < R && good; i0 += 256 * 4) {
+        unsigned long long v[4];
+        good = get_words<4>(msg + 2 * (size_t)PMSG_HDR, i0 + TIDX, 256, R, tag, a.abort_flag, v);
+        if (good) {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (i0 + TIDX + 256 * k < R) colq[i0 + TIDX + 256 * k] = u2d(v[k]);
+        }
+      }
+      if (!__syncthreads_and(good ? 1 : 0)) {
         ok = false;
         break;
       }
-      for (int k = 1 + TIDX; k <= 12; k += 256) s_hdr[k] = ld_agent(msg + k);
-      for (int i = TIDX; i < R; i += 256) colq[i] = u2d(ld_agent(msg + PMSG_HDR + i));
-      __syncthreads();
     }
     // ---- apply the step to the strip
     const int kind = (int)s_hdr[1];
@@ -1546,12 +1640,11 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
       continue;
     }
     // pivot: scaled pivot-row entries of the strip, objective row, devex weights -> next candidate first
-    double s_own = 0.0; // lanes 0..nc-1: s_j of the owned column
     const double s0 = xdiv(beta[p] - bound, piv);
     if (TIDX < nc) {
       const int j = j0 + TIDX;
       double *col = tile + (size_t)TIDX * R;
-      s_own = xdiv(col[p], piv);
+      const double s_own = xdiv(col[p], piv);
       const double dq = colq[0];
       col[0] = (j == q) ? xdiv(dq, piv) : fma(-dq, s_own, col[0]);
       if (j == q) {
@@ -1571,34 +1664,31 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
       my_nub = lv_ub;
       my_nflag = newflag;
     }
-    __syncthreads(); // everyone has read row p's old metadata and beta[p]
+    // s_j per owned column, for every lane: from the (still old) row p entries
+    double sc[PERSIST_MAX_CPW];
+    for (int cc = 0; cc < nc; cc++) sc[cc] = xdiv(tile[(size_t)cc * R + p], piv);
+    __syncthreads(); // everyone has read row p (entries, metadata) and beta[p]
     it++;
     publish_candidate(it + 1);
     // bulk update of the strip (rows 1..m; row 0 is done), column 0, metadata of row p
-    {
-      // s_j per owned column, for every lane: from the (still old) row p entries
-      double sc[PERSIST_MAX_CPW];
-      for (int cc = 0; cc < nc; cc++) sc[cc] = xdiv(tile[(size_t)cc * R + p], piv);
-      __syncthreads(); // row p is read by all before anyone overwrites it
-      for (int i = 1 + TIDX; i < R; i += 256) {
-        const double ci = colq[i];
-        if (i == p) {
-          for (int cc = 0; cc < nc; cc++) tile[(size_t)cc * R + i] = (j0 + cc == q) ? xdiv(1.0, piv) : -sc[cc];
-          beta[i] = xq - s0;
-        } else {
-          for (int cc = 0; cc < nc; cc++) {
-            double *e = tile + (size_t)cc * R + i;
-            *e = (j0 + cc == q) ? xdiv(ci, piv) : fma(-ci, sc[cc], *e);
-          }
-          beta[i] = fma(-ci, s0, beta[i]);
+    for (int i = 1 + TIDX; i < R; i += 256) {
+      const double ci = colq[i];
+      if (i == p) {
+        for (int cc = 0; cc < nc; cc++) tile[(size_t)cc * R + i] = (j0 + cc == q) ? xdiv(1.0, piv) : -sc[cc];
+        beta[i] = xq - s0;
+      } else {
+        for (int cc = 0; cc < nc; cc++) {
+          double *e = tile + (size_t)cc * R + i;
+          *e = (j0 + cc == q) ? xdiv(ci, piv) : fma(-ci, sc[cc], *e);
         }
+        beta[i] = fma(-ci, s0, beta[i]);
       }
-      if (TIDX == 0) {
-        beta[0] = fma(-colq[0], s0, beta[0]);
-        bvar[p] = ent_var;
-        blb[p] = ent_lb;
-        bub[p] = ent_ub;
-      }
+    }
+    if (TIDX == 0) {
+      beta[0] = fma(-colq[0], s0, beta[0]);
+      bvar[p] = ent_var;
+      blb[p] = ent_lb;
+      bub[p] = ent_ub;
     }
     it_cnt++;
     if (budget > 0) budget--;
@@ -1607,7 +1697,7 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
     __syncthreads();
   }
   if (!ok && TIDX == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- write the strip, column 0 and the metadata back (the tableau is consistent after any whole step)
+  // ---- write the strip, column 0 and the metadata back (the host restores its backup after an abort)
   __syncthreads();
   for (int i = TIDX; i < R; i += 256) {
     double *row = c->T + (size_t)i * ld;
@@ -1807,7 +1897,7 @@ __global__ __launch_bounds__(256) void k_gmi_backsub(GmiArgs a) {
 // LDS bytes of one k_persist workgroup: the strip, column 0, the pivot column, row bounds (f64) and basic variables (i32)
 size_t persist_lds_bytes(int m, int cpw) { return ((size_t)(m + 1) * (size_t)(cpw + 4)) * 8 + (size_t)(m + 1) * 4 + 64; }
 int persist_max_cpw() { return PERSIST_MAX_CPW; }
-int persist_msg_words(int m_cap) { return PMSG_HDR + m_cap + 1; }
+int persist_msg_words(int m_cap) { return 2 * (PMSG_HDR + m_cap + 1); }
 int launch_persist(Ctl *d_ctl, unsigned long long *cand, unsigned long long *msg, int *abort_flag, int m, int cpw, int nw, int msg_stride,
                    int max_steps, hipStream_t s) {
   static size_t attr_bytes = 0;

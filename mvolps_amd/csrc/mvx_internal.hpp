@@ -166,6 +166,8 @@ struct mvx_prob {
   int bland_cnt = 0; // pivots chosen under the anti-cycling (Bland) rule, diagnostic
   double last_ms = 0.0;
   double last_tol[3] = {0.0, 0.0, 0.0}; // tolerances of the solve that produced `status`
+  int piv_since_check = 0; // pivots since the residual of the row equations was last looked at (clones inherit it)
+  int refresh_cnt = 0;     // tableau refreshes, diagnostic
   bool hint_dual = false; // last edit made a basic variable infeasible: start in the dual simplex
   // bound edits of basic variables not yet on the device: (row position, lb, ub); the next solve's control block carries them
   struct Edit {

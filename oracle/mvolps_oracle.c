@@ -50,6 +50,8 @@ struct orc_prob {
   int it_cnt;
   int bland_cnt; /* pivots chosen by Bland's rule (diagnostic) */
   int pert_cnt;  /* bound perturbations applied (diagnostic) */
+  int piv_since_check; /* pivots since the residual of A x = x_R was last looked at (clones inherit it) */
+  int refresh_cnt;     /* tableau refreshes (diagnostic) */
 };
 
 /* a / b, correctly rounded -- the same function as xdiv() in mvolps_amd/csrc/kernels.hip.  On this side the
@@ -241,6 +243,8 @@ void orc_copy_prob(orc_prob *dst, const orc_prob *src, int names) {
   dst->valid = src->valid;
   dst->status = src->status;
   dst->it_cnt = src->it_cnt;
+  dst->piv_since_check = src->piv_since_check;
+  dst->refresh_cnt = src->refresh_cnt;
   dst->bland_cnt = src->bland_cnt;
   dst->pert_cnt = src->pert_cnt;
   if (src->valid) {
@@ -291,14 +295,18 @@ static int var_pos(const orc_prob *P, int k) {
   return 0;
 }
 
-static void build_slack_tableau(orc_prob *P) {
+static void build_slack_tableau_flags(orc_prob *P, const int *sflag);
+static void build_slack_tableau(orc_prob *P) { build_slack_tableau_flags(P, NULL); }
+
+/* sflag (nullable): non-basic status per structural column instead of the standard one (tableau refresh) */
+static void build_slack_tableau_flags(orc_prob *P, const int *sflag) {
   int m = P->m, n = P->n;
   P->ld = ((n + 1 + 7) / 8) * 8;
   free(P->T);
   P->T = (double *)xcalloc((size_t)(P->m_cap + 1) * P->ld, sizeof(double));
   for (int j = 1; j <= n; j++) {
     P->nvar[j] = m + j;
-    P->nflag[j] = std_flag(P->ctype[j]);
+    P->nflag[j] = sflag ? sflag[j] : std_flag(P->ctype[j]);
     P->nlb[j] = P->clb[j];
     P->nub[j] = P->cub[j];
   }
@@ -933,6 +941,86 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
   return ret;
 }
 
+/* ------------------------------------------------------------ tableau refresh
+   A dense tableau carries the rounding of every pivot it has been through (GLPK refactorises its basis behind
+   glp_simplex; a Gauss-Jordan tableau has nothing to refactorise).  Rule, identical in the HIP engine: a solve that
+   ends OPTIMAL on a handle with at least `check_every` pivots since the last look computes the residual of the row
+   equations, max_i |sum_j A_ij x_j - x_Ri| / (1 + |x_Ri|); above `tol` the tableau is REBUILT from the model for the
+   same basis -- slack tableau with every non-basic variable on the bound it sits at, then the basic structural
+   variables pivoted back in, in ascending variable number, each on the row of largest |entry| (lowest row on ties)
+   among the rows whose auxiliary has to leave -- and the simplex carries on from there. */
+static int g_check_every = 1024;
+static double g_refresh_tol = 1e-9;
+void orc_set_refresh(int check_every, double tol) {
+  g_check_every = check_every > 0 ? check_every : 1024;
+  g_refresh_tol = tol >= 0.0 ? tol : 1e-9;
+}
+int orc_get_refresh_cnt(const orc_prob *P) { return P->refresh_cnt; }
+
+static double var_value(const orc_prob *P, const int *pos, int k) {
+  int q = pos[k];
+  if (q > 0) return TT(P, q, 0);
+  double lb, ub;
+  if (k <= P->m) { lb = P->rlb[k]; ub = P->rub[k]; }
+  else { lb = P->clb[k - P->m]; ub = P->cub[k - P->m]; }
+  return nb_value(P->nflag[-q], lb, ub);
+}
+
+double orc_row_residual(const orc_prob *P) {
+  if (!P->valid) return 0.0;
+  int m = P->m, n = P->n;
+  int *pos = (int *)xcalloc((size_t)m + n + 1, sizeof(int));
+  for (int i = 1; i <= m; i++) pos[P->bvar[i]] = i;
+  for (int j = 1; j <= n; j++) pos[P->nvar[j]] = -j;
+  double *x = (double *)xcalloc((size_t)n + 1, sizeof(double));
+  for (int j = 1; j <= n; j++) x[j] = var_value(P, pos, m + j);
+  double worst = 0.0;
+  for (int i = 1; i <= m; i++) {
+    double acc = 0.0;
+    const double *a = P->A[i];
+    for (int j = 1; j <= n; j++) acc = acc + a[j] * x[j];
+    double xr = var_value(P, pos, i);
+    double r = fabs(acc - xr) / (1.0 + fabs(xr));
+    if (r > worst) worst = r;
+  }
+  free(pos); free(x);
+  return worst;
+}
+
+static void refresh_tableau(orc_prob *P) {
+  int m = P->m, n = P->n;
+  /* target: non-basic status by variable number, 0 = basic */
+  int *tflag = (int *)xcalloc((size_t)m + n + 1, sizeof(int));
+  for (int j = 1; j <= n; j++) tflag[P->nvar[j]] = P->nflag[j];
+  int *sflag = (int *)xcalloc((size_t)n + 1, sizeof(int));
+  for (int j = 1; j <= n; j++) sflag[j] = tflag[m + j] ? tflag[m + j] : std_flag(P->ctype[j]);
+  int it_keep = P->it_cnt, status = P->status;
+  build_slack_tableau_flags(P, sflag);
+  for (int k = m + 1; k <= m + n; k++) {
+    if (tflag[k]) continue; /* non-basic in the target basis */
+    int q = 0;
+    for (int j = 1; j <= n; j++)
+      if (P->nvar[j] == k) { q = j; break; }
+    if (!q) continue;
+    int p = 0;
+    double best = 0.0;
+    for (int i = 1; i <= m; i++) {
+      int v = P->bvar[i];
+      if (v > m || !tflag[v]) continue; /* only rows whose auxiliary has to leave */
+      double mag = fabs(TT(P, i, q));
+      if (mag > best) { best = mag; p = i; } /* strict >: lowest row on ties */
+    }
+    if (!p) continue; /* numerically singular for this column: the simplex run that follows sorts it out */
+    int tf = tflag[P->bvar[p]];
+    double bound = (tf == ORC_NU) ? P->bub[p] : (tf == ORC_NF ? 0.0 : P->blb[p]);
+    pivot(P, p, q, bound, tf, NULL);
+  }
+  P->it_cnt = it_keep;
+  P->status = status;
+  P->refresh_cnt++;
+  free(tflag); free(sflag);
+}
+
 static double g_tol_bnd = 1e-9, g_tol_dj = 1e-9, g_tol_piv = 1e-9; /* behind parm == NULL; see mvx_set_default_tolerances */
 void orc_set_default_tolerances(double tol_bnd, double tol_dj, double tol_piv) {
   g_tol_bnd = tol_bnd;
@@ -949,7 +1037,25 @@ void orc_init_smcp(orc_smcp *parm) {
   parm->tol_piv = g_tol_piv;
 }
 
+static int simplex_once(orc_prob *P, const orc_smcp *parm);
+
 int orc_simplex(orc_prob *P, const orc_smcp *parm) {
+  int before = P->it_cnt;
+  int rc = simplex_once(P, parm);
+  P->piv_since_check += P->it_cnt - before;
+  if (rc == 0 && P->status == ORC_OPT && P->piv_since_check >= g_check_every) {
+    P->piv_since_check = 0;
+    if (orc_row_residual(P) > g_refresh_tol) {
+      refresh_tableau(P);
+      before = P->it_cnt;
+      rc = simplex_once(P, parm); /* the pivot limit of the call, if any, applies to this leg afresh */
+      P->piv_since_check += P->it_cnt - before;
+    }
+  }
+  return rc;
+}
+
+static int simplex_once(orc_prob *P, const orc_smcp *parm) {
   orc_smcp dflt;
   if (!parm) {
     orc_init_smcp(&dflt);
@@ -1163,7 +1269,7 @@ int orc_get_basis(const orc_prob *P, int *head, int *nb, int *flag) {
 /* Host-memory counterpart of mvx_pack_from / mvx_unpack (world_size-2 gloo tests run the coordinator over this
    library): rows 1..m_base of the model are the receiver's own, the rows appended since (cut rows) travel. */
 typedef struct {
-  long long magic, m, n, ld, status, it_cnt, valid, m_base;
+  long long magic, m, n, ld, status, it_cnt, valid, m_base, piv_since_check, reserved;
 } pack_hdr;
 #define PACK_MAGIC 0x4d56584f5244ll
 
@@ -1182,7 +1288,7 @@ static int pack_from(const orc_prob *P, int m_base, void *buf) {
   int m = P->m, n = P->n;
   if (m_base < 0 || m_base > m) return -1;
   unsigned char *b = (unsigned char *)buf;
-  pack_hdr h = {PACK_MAGIC, m, n, P->ld, P->status, P->it_cnt, P->valid, m_base};
+  pack_hdr h = {PACK_MAGIC, m, n, P->ld, P->status, P->it_cnt, P->valid, m_base, P->piv_since_check, 0};
   memcpy(b, &h, sizeof(h)); b += sizeof(h);
   unsigned char *b0 = b;
 #define PUT(ptr, cnt, T) do { memcpy(b, (ptr), (size_t)(cnt) * sizeof(T)); b += (size_t)(cnt) * sizeof(T); } while (0)
@@ -1234,6 +1340,7 @@ int orc_unpack(orc_prob *dst, const orc_prob *base, const void *buf) {
   for (int i = m_base + 1; i <= m; i++) GET(dst->A[i], n + 1, double);
   dst->status = (int)h.status;
   dst->it_cnt = (int)h.it_cnt;
+  dst->piv_since_check = (int)h.piv_since_check;
   dst->valid = (int)h.valid;
   if (h.valid) {
     dst->ld = (int)h.ld;

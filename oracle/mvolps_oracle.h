@@ -91,6 +91,10 @@ int orc_load_dense(orc_prob *P, int m, int n, const double *A, const double *b, 
 /* solve (bs.cpp:117,279,287) */
 void orc_init_smcp(orc_smcp *parm);
 void orc_set_default_tolerances(double tol_bnd, double tol_dj, double tol_piv);
+/* tableau refresh (see mvolps_oracle.c): residual look every `check_every` pivots of a lineage, rebuild above `tol` */
+void orc_set_refresh(int check_every, double tol);
+int orc_get_refresh_cnt(const orc_prob *P);
+double orc_row_residual(const orc_prob *P);
 int orc_simplex(orc_prob *P, const orc_smcp *parm);
 /* same contract as mvx_simplex_batch; here simply one after the other */
 int orc_simplex_batch(orc_prob **probs, int count, const orc_smcp *parm, int *rcs);

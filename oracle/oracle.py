@@ -79,6 +79,9 @@ def api():
             "printInfo_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "generateCut3": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
             "generateCutGMI": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+            "set_refresh": (None, [C.c_int, C.c_double]),
+            "get_refresh_cnt": (C.c_int, [C.c_void_p]),
+            "row_residual": (C.c_double, [C.c_void_p]),
             "pack_size": (C.c_longlong, [C.c_void_p]),
             "pack": (C.c_int, [C.c_void_p, C.c_void_p]),
             "pack_size_from": (C.c_longlong, [C.c_void_p, C.c_void_p]),
