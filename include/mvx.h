@@ -198,6 +198,9 @@ double mvx_row_residual(const mvx_prob *P);
    identical either way.  mvx_persist_stats: launches made / launches that aborted and were redone by the two-kernel path */
 void mvx_set_persist(int mode);
 void mvx_persist_stats(long long *launches, long long *aborts);
+/* shader-clock cycles workgroup 0 spent per phase of the resident-tableau loop, summed over launches: propose, gather,
+   read, apply; out5[4] = pivots */
+void mvx_persist_cycles(unsigned long long *out5);
 /* number of handles that share one launch in mvx_simplex_batch (default 64, 2..256) */
 void mvx_set_batch_slots(int slots);
 /* block until all work queued on the engine stream has finished */

@@ -62,9 +62,9 @@ void launch_gmi(const GmiArgs &a, hipStream_t);
 void launch_refresh_select(Ctl *, const int *tflag, int var, hipStream_t);
 size_t persist_lds_bytes(int m, int cpw);
 int persist_max_cpw();
-int persist_msg_words(int m_cap);
-int launch_persist(Ctl *, unsigned long long *cand, unsigned long long *msg, int *abort_flag, int m, int cpw, int nw, int msg_stride,
-                   int max_steps, hipStream_t);
+int persist_slot_words(int m_cap);
+int launch_persist(Ctl *, unsigned long long *head, unsigned long long *slot, int *abort_flag, unsigned long long *dbg, int m, int cpw, int nw,
+                   int slot_stride, int max_steps, int head_stride, hipStream_t);
 void launch_rowcomb(Ctl *, int m, int n, int respect_done, hipStream_t);
 void launch_shift_nonbasic(double *T, int ld, int m, int jj, double delta, hipStream_t);
 void launch_set_basic_bounds(double *blb, double *bub, int i, double lb, double ub, hipStream_t);
@@ -691,6 +691,7 @@ static void flush_update_events(Context &c, size_t used) {
 // A solve is a small host-side state machine around queued launches, so that several of them
 // can be in flight on different streams (engine_simplex_batch): begin -> {enqueue, sync, collect}*.
 // ---- resident-tableau path (k_persist): which problems take it, its buffers, backup and restore
+constexpr int PERSIST_HEAD_STRIDE_MAX = 1024; // granules (8 KB) between two strips' heads at most
 static int g_persist_mode = -1;      // -1: environment MVX_PERSIST (default on), 0 off, 1 on
 static bool g_persist_broken = false; // a launch aborted (its workgroups were not co-resident in time): off for good
 static long long g_persist_launches = 0, g_persist_aborts = 0;
@@ -702,7 +703,7 @@ static bool persist_plan(Context &c, const mvx_prob *P, PersistPlan *pl) {
   if (g_persist_broken) return false;
   if (g_persist_mode < 0) {
     const char *e = std::getenv("MVX_PERSIST");
-    g_persist_mode = (e && e[0] == '0') ? 0 : 1;
+    g_persist_mode = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1);
   }
   if (!g_persist_mode) return false;
   static int cus = 0;
@@ -713,28 +714,33 @@ static bool persist_plan(Context &c, const mvx_prob *P, PersistPlan *pl) {
   }
   const int m = P->m, n = P->n;
   if ((long)(m + 1) * (n + 1) < 32768) return false; // a handful of pivots: the launch is not worth its set-up
+  // Measured (profiles/r02_persist_ab.jsonl): 256x512 29.6 -> 10.6 us/pivot, 512x1024 16.0 -> 12.1, 1024x2048 15.9 -> 15.6,
+  // 1024x4096 20.3 -> 20.2: the per-pivot gather of the 256 proposals costs ~6.5 us whatever the size (3.6 polling sweeps
+  // of ~1.8 us each), the strip work grows with m.  MVX_PERSIST=2 lifts the size cap for experiments.
+  if (g_persist_mode < 2 && (long)(m + 1) * (n + 1) > 700000) return false;
   const int cpw = (n + cus - 1) / cus;
   if (cpw > persist_max_cpw()) return false;
   pl->cpw = cpw;
   pl->nw = (n + cpw - 1) / cpw; // one workgroup per CU at most: every workgroup must be resident at once
+  if (pl->nw > 256) return false; // the exchange buffers are sized for 256 workgroups
   pl->lds = persist_lds_bytes(m, cpw);
   return pl->lds <= (size_t)150 * 1024;
 }
 
 static bool ensure_persist(Context &c, SolveCtx &sc, const mvx_prob *P, const PersistPlan &pl) {
-  const int words = persist_msg_words(P->m_cap);
+  const int words = persist_slot_words(P->m_cap);
   if (!sc.d_pabort) {
     HIPCHECK(hipMalloc((void **)&sc.d_pabort, 256));
     HIPCHECK(hipMemsetAsync(sc.d_pabort, 0, 256, sc.stream));
     HIPCHECK(hipHostMalloc((void **)&sc.h_pabort, 256));
     sc.h_pabort[0] = 0;
-    HIPCHECK(hipMalloc((void **)&sc.d_pcand, (size_t)2 * 256 * 3 * 8 * 4));
+    HIPCHECK(hipMalloc((void **)&sc.d_pcand, (size_t)2 * 256 * PERSIST_HEAD_STRIDE_MAX * 8));
     HIPCHECK(hipMalloc((void **)&sc.d_pctl, sizeof(Ctl)));
   }
   if (words > sc.p_msg_words) {
     HIPCHECK(hipStreamSynchronize(sc.stream));
     if (sc.d_pmsg) HIPCHECK(hipFree(sc.d_pmsg));
-    HIPCHECK(hipMalloc((void **)&sc.d_pmsg, (size_t)2 * words * 8));
+    HIPCHECK(hipMalloc((void **)&sc.d_pmsg, (size_t)2 * 256 * words * 8)); // a slot per workgroup and parity
     sc.p_msg_words = words;
   }
   if (P->ld > sc.p_pw_ld) {
@@ -781,7 +787,7 @@ static int pivot_budget(const mvx_prob *P, const mvx_smcp &parm) {
 static void stage_copy_async(SolveCtx &sc, const mvx_prob *P) {
   HIPCHECK(hipEventRecord(sc.ev_b, sc.stream)); // end of the device work queued so far (last_solve_ms)
   HIPCHECK(hipMemcpyAsync(sc.h_stage, sc.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, sc.stream));
-  if (sc.d_pabort) HIPCHECK(hipMemcpyAsync(sc.h_pabort, sc.d_pabort, sizeof(int), hipMemcpyDeviceToHost, sc.stream));
+  if (sc.d_pabort) HIPCHECK(hipMemcpyAsync(sc.h_pabort, sc.d_pabort, 128, hipMemcpyDeviceToHost, sc.stream)); // abort flag + phase cycle totals
 }
 
 static void job_begin(Context &c, SolveJob &J) {
@@ -863,10 +869,15 @@ static void job_enqueue(Context &c, SolveJob &J) {
         HIPCHECK(hipMemcpyAsync(sc.d_pctl, sc.d_ctl, sizeof(Ctl), hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw, sc.d_pw[0], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw + P->ld, sc.d_pw[1], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
-        HIPCHECK(hipMemsetAsync(sc.d_pcand, 0, (size_t)2 * pl.nw * 4 * 8, sc.stream));
-        HIPCHECK(hipMemsetAsync(sc.d_pmsg, 0, (size_t)2 * sc.p_msg_words * 8, sc.stream));
+        static int head_stride = 0;
+        if (!head_stride) {
+          const char *e = std::getenv("MVX_PERSIST_HS");
+          head_stride = e ? std::atoi(e) : 4;
+          if (head_stride < 4 || head_stride > PERSIST_HEAD_STRIDE_MAX) head_stride = 4;
+        }
+        HIPCHECK(hipMemsetAsync(sc.d_pcand, 0, (size_t)2 * pl.nw * head_stride * 8, sc.stream));
         const int steps = 1 << 24; // the pivot limit is the control block's `budget`, which the kernel counts down
-        if (launch_persist(sc.d_ctl, sc.d_pcand, sc.d_pmsg, sc.d_pabort, P->m, pl.cpw, pl.nw, sc.p_msg_words, steps, sc.stream) == 0) {
+        if (launch_persist(sc.d_ctl, sc.d_pcand, sc.d_pmsg, sc.d_pabort, (unsigned long long *)(sc.d_pabort + 16), P->m, pl.cpw, pl.nw, sc.p_msg_words, steps, head_stride, sc.stream) == 0) {
           J.persist_queued = true;
           g_persist_launches++;
           // what the run ended on (optimum, unbounded ray, stall, pivot limit) is settled by one generic step
@@ -1915,12 +1926,19 @@ void tuning(int tr, int hot, int nt) {
 }
 
 void set_persist(int mode) {
-  g_persist_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  g_persist_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode); // 2: no size cap
   g_persist_broken = false;
 }
 void persist_stats(long long *launches, long long *aborts) {
   *launches = g_persist_launches;
   *aborts = g_persist_aborts;
+}
+// cycle totals of workgroup 0 per phase since the context was created: propose, gather, read, apply, pivots
+void persist_cycles(unsigned long long *out5) {
+  for (int k = 0; k < 7; k++) out5[k] = 0;
+  if (!g_ctx || !g_ctx->main.h_pabort) return;
+  const unsigned long long *d = (const unsigned long long *)(g_ctx->main.h_pabort + 16);
+  for (int k = 0; k < 7; k++) out5[k] = d[k];
 }
 void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }

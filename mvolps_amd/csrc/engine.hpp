@@ -40,6 +40,7 @@ void set_persist(int mode);
 void set_refresh(int check_every, double tol);
 double row_residual(const mvx_prob *P);
 void persist_stats(long long *launches, long long *aborts);
+void persist_cycles(unsigned long long *out5);
 void set_batch_slots(int k);
 void profile_enable(int on);
 void profile_reset();

@@ -1371,23 +1371,27 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 // bandwidth: two dependent launches per pivot cost ~14 us where the bytes would take ~4.  k_persist keeps
 // the whole tableau ON CHIP for hundreds of pivots: one launch, one workgroup per CU, each owning a strip
 // of CPW consecutive columns in its LDS (column-major, so that a lane walks rows conflict-free), plus its
-// own replica of column 0 (basic values) and of the per-row metadata (basic variable, bounds).  Per pivot
-// only three things cross workgroups, through agent-scope 8-byte atomics (MI355X_MICROARCH.md, inter-
-// workgroup visibility: "8-B agent atomics both sides" / sc1 payload + drained flag):
-//   1. every workgroup's best entering candidate of its strip (three self-tagged granules), gathered by all;
-//   2. from the workgroup that owns the chosen column q: the pivot description and column q itself;
-// everything else -- scaled pivot-row entries, the rank-1 update of the strip, devex weights, the next
-// pricing -- is local.  The next candidate is published BEFORE the bulk update of the strip, so the gather
-// overlaps it.  Arithmetic per entry is that of k_fa / k_fb / the oracle; every wait is bounded and ends in
-// a shared abort flag, so the grid always drains (the host then falls back on k_fa / k_fb for good).
+// own replica of column 0 (basic values) and of the per-row metadata (basic variable, bounds).
+// One exchange per pivot: after applying a step, EVERY workgroup prices its strip, runs the ratio test on its
+// own best column as if that column were going to enter, writes the column and the pivot description into its
+// slot of a global buffer (8-byte agent-scope stores, drained), and only then publishes a two-word head
+// {score, column} as self-tagged granules.  Every workgroup gathers the 256 heads (all loads of a sweep in
+// flight), reduces them to the winner, and reads the winner's slot -- which is complete, because its head was
+// published after the drain (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload, every storing wave's
+// vmcnt(0), workgroup barrier, then the tagged word).  Everything else -- scaled pivot-row entries, the rank-1
+// update of the strip, devex weights -- is local.  Arithmetic per entry is that of k_fa / k_fb / the oracle;
+// every wait is bounded and ends in a shared abort flag, so the grid always drains (the host then restores its
+// backup and falls back on k_fa / k_fb for good).
 struct PersistArgs {
   Ctl *ctl;
-  unsigned long long *cand; // [2][nw][2] tagged candidate granules
-  unsigned long long *msg;  // [2][2 * (PMSG_HDR + m_cap + 1)] pivot message: header + column q, two tagged granules per word
+  unsigned long long *head; // [2][nw][2 words x 2 granules] tagged {score}, {column, direction}
+  unsigned long long *slot; // [2][nw][slot_stride] pivot description (PMSG_HDR words) + the candidate column
   int *abort_flag;
-  int cpw, nw, msg_stride, max_steps;
+  unsigned long long *dbg; // [8] cycle totals of workgroup 0 per phase (propose, gather, read, apply), pivots
+  int cpw, nw, slot_stride, max_steps;
+  int head_stride; // granules between two strips' heads (>= 4): spreads the heads over memory channels
 };
-constexpr int PMSG_HDR = 16; // 64-bit words in front of the column in a pivot message
+constexpr int PMSG_HDR = 16; // 64-bit words in front of the column in a slot
 constexpr int PERSIST_SPIN = 1 << 20;
 constexpr int PERSIST_MAX_CPW = 16;
 
@@ -1446,6 +1450,8 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
   extern __shared__ double smem[];
   __shared__ Cand lds[17];
   __shared__ unsigned long long s_hdr[PMSG_HDR];
+  __shared__ unsigned s_gran[1024]; // low halves of the gathered head granules
+  __shared__ double s_sc[PERSIST_MAX_CPW]; // scaled pivot-row entries of the strip
   __shared__ int s_ok;
   Ctl *c = a.ctl;
   if (c->done != D_RUN || c->phase != PH_PRIMAL2 || c->stall >= c->stall_limit || c->budget == 0 || c->perturbed) return;
@@ -1490,50 +1496,120 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
   bool ok = true;
   int steps = 0;
   unsigned it = 0; // iteration number; tags are it + 1
-  auto publish_candidate = [&](unsigned tag) {
-    // lanes 0..nc-1 price their column, wave 0 reduces, lane 0 publishes: {score} and {column, direction}
-    if (TIDX < 64) {
+  long long t_prop = 0, t_gath = 0, t_read = 0, t_appl = 0, n_sweeps = 0, t_first = 0;
+  while (ok) {
+    const long long c0 = clock64();
+    const unsigned tag = it + 1;
+    unsigned long long *myslot = a.slot + ((size_t)(tag & 1) * a.nw + w) * a.slot_stride;
+    // ---- this strip's proposal: best column of the strip, and the whole step it would make
+    {
       Cand best{0.0, 0.0, 0, 0};
-      if (TIDX < nc) {
-        Cand x;
-        if (price_col(my_nflag, sgn * tile[(size_t)TIDX * R], tol_dj, j0 + TIDX, my_w, x)) best = x;
+      if (TIDX < 64) {
+        if (TIDX < nc) {
+          Cand x;
+          if (price_col(my_nflag, sgn * tile[(size_t)TIDX * R], tol_dj, j0 + TIDX, my_w, x)) best = x;
+        }
+        best = wave_best<0>(best);
+        if (TIDX == 0) lds[16] = best;
       }
-      best = wave_best<0>(best);
+      __syncthreads();
+      best = lds[16];
+      __syncthreads(); // lds is reused by the ratio test
+      const int q = best.idx, sdir = best.aux;
+      if (q) {
+        const int cq = q - j0;
+        const double *col = tile + (size_t)cq * R;
+        Cand rb{0.0, 0.0, 0, 0};
+        for (int i = 1 + TIDX; i < R; i += 256) {
+          Cand x;
+          if (ratio_row(col[i], sdir, beta[i], blb[i], bub[i], 0, tol_piv, i, x) && cand_better<1>(x, rb)) rb = x;
+        }
+        const Cand r = block_best<1>(rb, lds);
+        // the column's own bounds / status live in lane cq of wave 0
+        const double lbq = __shfl(my_nlb, cq, 64), ubq = __shfl(my_nub, cq, 64), wq = __shfl(my_w, cq, 64);
+        const int fq = __shfl(my_nflag, cq, 64), vq = __shfl(my_nvar, cq, 64);
+        if (TIDX == 0) {
+          int kind = ST_PIVOT; // ST_PIVOT / ST_FLIP / ST_STOP
+          double delta = 0.0;
+          if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+            const double tf = ubq - lbq;
+            if (r.idx == 0 || tf <= r.k1) {
+              kind = ST_FLIP;
+              delta = (sdir > 0) ? tf : -tf;
+            }
+          }
+          if (kind == ST_PIVOT && r.idx == 0) kind = ST_STOP; // unbounded ray: the generic path reports it
+          const int p = r.idx, p_up = r.aux;
+          st_agent(myslot + 1, (unsigned long long)kind);
+          st_agent(myslot + 2, (unsigned long long)(unsigned)p | ((unsigned long long)(unsigned)p_up << 32));
+          st_agent(myslot + 3, d2u(p ? col[p] : 1.0));                          // piv
+          st_agent(myslot + 4, d2u(p ? (p_up ? bub[p] : blb[p]) : 0.0));          // bound
+          st_agent(myslot + 5, d2u(dev_nb_value(fq, lbq, ubq)));                 // xq
+          st_agent(myslot + 6, d2u(lbq));
+          st_agent(myslot + 7, d2u(ubq));
+          st_agent(myslot + 8, d2u(delta));
+          st_agent(myslot + 9, d2u(wq));
+          st_agent(myslot + 10, (unsigned long long)(unsigned)vq);
+          st_agent(myslot + 11, d2u(r.k1));
+          st_agent(myslot + 12, (unsigned long long)(unsigned)((kind == ST_FLIP) ? ((sdir > 0) ? MVX_NU : MVX_NL) : (p ? dev_leave_flag(blb[p], bub[p], p_up) : 0)));
+        }
+        for (int i = TIDX; i < R; i += 256) st_agent(myslot + PMSG_HDR + i, d2u(col[i]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the head goes out
+      }
+      __syncthreads();
       if (TIDX == 0) {
-        unsigned long long *g = a.cand + ((size_t)(tag & 1) * a.nw + w) * 4;
+        unsigned long long *g = a.head + ((size_t)(tag & 1) * a.nw + w) * a.head_stride;
         put_word(g, d2u(best.k1), tag);
         put_word(g + 2, ((unsigned long long)(unsigned)best.idx << 1) | (best.aux > 0 ? 1ull : 0ull), tag);
       }
     }
-  };
-  publish_candidate(1);
-  while (ok) {
-    const unsigned tag = it + 1;
-    // ---- gather every strip's candidate (wave 0: up to four strips per lane, all loads in flight), reduce
+    const long long c1 = clock64();
+    t_prop += c1 - c0;
+    // ---- gather every strip's head: wave 0, lane l taking strips l, l + 64, ... (four granules each, all loads of a
+    // sweep in flight), re-reading only what has not arrived
     if (TIDX < 64) {
-      const unsigned long long *g = a.cand + (size_t)(tag & 1) * a.nw * 4;
-      unsigned long long wd[8];
-      // words 2k (score) and 2k+1 (column) of strip TIDX + 64 * (k / ...): laid out as [strip][2 words]
-      bool good = true;
-      Cand best{0.0, 0.0, 0, 0};
-      {
-        unsigned long long sc[4], mt[4];
-        good = get_words<4>(g, 2 * TIDX, 128, 2 * a.nw, tag, a.abort_flag, sc);
-        good = good && get_words<4>(g, 2 * TIDX + 1, 128, 2 * a.nw, tag, a.abort_flag, mt);
-        if (good) {
+      const unsigned long long *g = a.head + (size_t)(tag & 1) * a.nw * a.head_stride;
+      unsigned pend = 0;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            if (TIDX + 64 * k >= a.nw) continue;
-            const int idx = (int)(mt[k] >> 1);
-            if (idx) {
-              Cand x{u2d(sc[k]), 0.0, idx, (mt[k] & 1ull) ? 1 : -1};
-              if (cand_better<0>(x, best)) best = x;
-            }
+      for (int k = 0; k < 16; k++)
+        if (TIDX + 64 * (k >> 2) < a.nw) pend |= 1u << k;
+      bool good = true;
+      for (int spin = 0; spin < PERSIST_SPIN; spin++) {
+        unsigned long long v[16];
+        n_sweeps++;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (pend & (1u << k)) v[k] = ld_agent(g + (size_t)(TIDX + 64 * (k >> 2)) * a.head_stride + (k & 3));
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if ((pend & (1u << k)) && (unsigned)(v[k] >> 32) == tag) {
+            s_gran[4 * (TIDX + 64 * (k >> 2)) + (k & 3)] = (unsigned)v[k];
+            pend &= ~(1u << k);
           }
+        if (spin == 0) t_first += clock64() - c1;
+        if (__all(pend == 0)) break;
+        if ((spin & 63) == 63) {
+          if (persist_aborted(a.abort_flag)) {
+            good = false;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
         }
-        (void)wd;
+        if (spin == PERSIST_SPIN - 1) good = false;
       }
       const int allgood = __all(good ? 1 : 0);
+      Cand best{0.0, 0.0, 0, 0};
+      if (allgood) {
+        for (int st = TIDX; st < a.nw; st += 64) {
+          const unsigned long long sc = ((unsigned long long)s_gran[4 * st] << 32) | s_gran[4 * st + 1];
+          const unsigned long long mt = ((unsigned long long)s_gran[4 * st + 2] << 32) | s_gran[4 * st + 3];
+          const int idx = (int)(mt >> 1);
+          if (idx) {
+            Cand x{u2d(sc), 0.0, idx, (mt & 1ull) ? 1 : -1};
+            if (cand_better<0>(x, best)) best = x;
+          }
+        }
+      }
       best = wave_best<0>(best);
       if (TIDX == 0) {
         lds[16] = best;
@@ -1545,82 +1621,34 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
       ok = false;
       break;
     }
+    const long long c2 = clock64();
+    t_gath += c2 - c1;
     const Cand ent = lds[16];
-    const int q = ent.idx, sdir = ent.aux;
+    const int q = ent.idx;
     if (q == 0 || budget == 0 || stall >= stall_limit || steps >= a.max_steps) break; // the generic path takes over
     const int owner = (q - 1) / cpw;
-    unsigned long long *msg = a.msg + (size_t)(tag & 1) * a.msg_stride;
-    __syncthreads(); // lds[16] / s_ok are reused below
-    if (owner == w) {
-      // ---- ratio test on the owned column, then the pivot message (every word self-tagged: no flag)
-      const int cq = q - j0;
-      const double *col = tile + (size_t)cq * R;
-      Cand best{0.0, 0.0, 0, 0};
-      for (int i = 1 + TIDX; i < R; i += 256) {
-        Cand x;
-        if (ratio_row(col[i], sdir, beta[i], blb[i], bub[i], 0, tol_piv, i, x) && cand_better<1>(x, best)) best = x;
-      }
-      const Cand r = block_best<1>(best, lds);
-      // the entering column's own bounds / status live in lane cq of wave 0
-      const double lbq = __shfl(my_nlb, cq, 64), ubq = __shfl(my_nub, cq, 64), wq = __shfl(my_w, cq, 64);
-      const int fq = __shfl(my_nflag, cq, 64), vq = __shfl(my_nvar, cq, 64);
-      if (TIDX == 0) {
-        int kind = ST_PIVOT; // ST_PIVOT / ST_FLIP / ST_STOP
-        double delta = 0.0;
-        if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
-          const double tf = ubq - lbq;
-          if (r.idx == 0 || tf <= r.k1) {
-            kind = ST_FLIP;
-            delta = (sdir > 0) ? tf : -tf;
-          }
-        }
-        if (kind == ST_PIVOT && r.idx == 0) kind = ST_STOP; // unbounded ray: the generic path reports it
-        const int p = r.idx, p_up = r.aux;
-        const double piv = p ? col[p] : 1.0;
-        const double bound = p ? (p_up ? bub[p] : blb[p]) : 0.0;
-        s_hdr[1] = (unsigned long long)kind;
-        s_hdr[2] = (unsigned long long)(unsigned)p | ((unsigned long long)(unsigned)p_up << 32);
-        s_hdr[3] = d2u(piv);
-        s_hdr[4] = d2u(bound);
-        s_hdr[5] = d2u(dev_nb_value(fq, lbq, ubq)); // xq
-        s_hdr[6] = d2u(lbq);
-        s_hdr[7] = d2u(ubq);
-        s_hdr[8] = d2u(delta);
-        s_hdr[9] = d2u(wq);
-        s_hdr[10] = (unsigned long long)(unsigned)vq;
-        s_hdr[11] = d2u(r.k1);
-        s_hdr[12] = (unsigned long long)(unsigned)((kind == ST_FLIP) ? ((sdir > 0) ? MVX_NU : MVX_NL) : (p ? dev_leave_flag(blb[p], bub[p], p_up) : 0));
-      }
-      __syncthreads();
-      if (TIDX >= 1 && TIDX <= 12) put_word(msg + 2 * TIDX, s_hdr[TIDX], tag);
-      for (int i = TIDX; i < R; i += 256) {
-        const double v = col[i];
-        colq[i] = v;
-        put_word(msg + 2 * (size_t)(PMSG_HDR + i), d2u(v), tag);
-      }
-      __syncthreads();
-    } else {
-      // header (lanes 1..12) and column q (every lane: rows TIDX, TIDX + 256, ...), one sweep of loads each
-      bool good = true;
-      if (TIDX >= 1 && TIDX <= 12) {
-        unsigned long long v[1];
-        good = get_words<1>(msg, TIDX, 1, PMSG_HDR, tag, a.abort_flag, v);
-        if (good) s_hdr[TIDX] = v[0];
-      }
-      for (int i0 = 0; i0 < R && good; i0 += 256 * 4) {
-        unsigned long long v[4];
-        good = get_words<4>(msg + 2 * (size_t)PMSG_HDR, i0 + TIDX, 256, R, tag, a.abort_flag, v);
-        if (good) {
+    // ---- the winner's slot: complete since its head was published after the drain
+    {
+      const unsigned long long *ws = a.slot + ((size_t)(tag & 1) * a.nw + owner) * a.slot_stride;
+      if (TIDX >= 1 && TIDX <= 12) s_hdr[TIDX] = ld_agent(ws + TIDX);
+      if (owner == w) {
+        const double *col = tile + (size_t)(q - j0) * R;
+        for (int i = TIDX; i < R; i += 256) colq[i] = col[i];
+      } else {
+        for (int i0 = 0; i0 < R; i0 += 1024) {
+          unsigned long long v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (i0 + TIDX + 256 * k < R) v[k] = ld_agent(ws + PMSG_HDR + i0 + TIDX + 256 * k);
 #pragma unroll
           for (int k = 0; k < 4; k++)
             if (i0 + TIDX + 256 * k < R) colq[i0 + TIDX + 256 * k] = u2d(v[k]);
         }
       }
-      if (!__syncthreads_and(good ? 1 : 0)) {
-        ok = false;
-        break;
-      }
+      __syncthreads();
     }
+    const long long c3 = clock64();
+    t_read += c3 - c2;
     // ---- apply the step to the strip
     const int kind = (int)s_hdr[1];
     if (kind == ST_STOP) break;
@@ -1634,17 +1662,17 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
       if (owner == w && TIDX == q - j0) my_nflag = newflag;
       n_flips++;
       stall = 0;
-      __syncthreads();
       it++;
-      publish_candidate(it + 1);
+      __syncthreads();
       continue;
     }
-    // pivot: scaled pivot-row entries of the strip, objective row, devex weights -> next candidate first
+    // pivot: scaled pivot-row entries of the strip, objective row, devex weights
     const double s0 = xdiv(beta[p] - bound, piv);
     if (TIDX < nc) {
       const int j = j0 + TIDX;
       double *col = tile + (size_t)TIDX * R;
       const double s_own = xdiv(col[p], piv);
+      s_sc[TIDX] = s_own;
       const double dq = colq[0];
       col[0] = (j == q) ? xdiv(dq, piv) : fma(-dq, s_own, col[0]);
       if (j == q) {
@@ -1664,25 +1692,24 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
       my_nub = lv_ub;
       my_nflag = newflag;
     }
-    // s_j per owned column, for every lane: from the (still old) row p entries
+    __syncthreads(); // s_sc is complete; everyone has read row p's metadata and beta[p]
     double sc[PERSIST_MAX_CPW];
-    for (int cc = 0; cc < nc; cc++) sc[cc] = xdiv(tile[(size_t)cc * R + p], piv);
-    __syncthreads(); // everyone has read row p (entries, metadata) and beta[p]
-    it++;
-    publish_candidate(it + 1);
+    for (int cc = 0; cc < nc; cc++) sc[cc] = s_sc[cc];
+    const int cq = (owner == w) ? q - j0 : -1; // the entering column, when it lives in this strip
     // bulk update of the strip (rows 1..m; row 0 is done), column 0, metadata of row p
     for (int i = 1 + TIDX; i < R; i += 256) {
       const double ci = colq[i];
       if (i == p) {
-        for (int cc = 0; cc < nc; cc++) tile[(size_t)cc * R + i] = (j0 + cc == q) ? xdiv(1.0, piv) : -sc[cc];
+        for (int cc = 0; cc < nc; cc++) tile[(size_t)cc * R + i] = -sc[cc];
         beta[i] = xq - s0;
       } else {
         for (int cc = 0; cc < nc; cc++) {
           double *e = tile + (size_t)cc * R + i;
-          *e = (j0 + cc == q) ? xdiv(ci, piv) : fma(-ci, sc[cc], *e);
+          *e = fma(-ci, sc[cc], *e);
         }
         beta[i] = fma(-ci, s0, beta[i]);
       }
+      if (cq >= 0) tile[(size_t)cq * R + i] = (i == p) ? xdiv(1.0, piv) : xdiv(ci, piv); // column q: T[i][q] = old / piv
     }
     if (TIDX == 0) {
       beta[0] = fma(-colq[0], s0, beta[0]);
@@ -1694,7 +1721,14 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
     if (budget > 0) budget--;
     stall = (step_len <= DEGEN_TOL) ? stall + 1 : 0;
     steps++;
+    it++;
     __syncthreads();
+    t_appl += clock64() - c3;
+  }
+  if (w == 0 && TIDX == 0 && a.dbg) {
+    a.dbg[0] += (unsigned long long)t_prop; a.dbg[1] += (unsigned long long)t_gath; a.dbg[2] += (unsigned long long)t_read;
+    a.dbg[3] += (unsigned long long)t_appl; a.dbg[4] += (unsigned long long)steps;
+    a.dbg[5] += (unsigned long long)n_sweeps; a.dbg[6] += (unsigned long long)t_first;
   }
   if (!ok && TIDX == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- write the strip, column 0 and the metadata back (the host restores its backup after an abort)
@@ -1897,9 +1931,9 @@ __global__ __launch_bounds__(256) void k_gmi_backsub(GmiArgs a) {
 // LDS bytes of one k_persist workgroup: the strip, column 0, the pivot column, row bounds (f64) and basic variables (i32)
 size_t persist_lds_bytes(int m, int cpw) { return ((size_t)(m + 1) * (size_t)(cpw + 4)) * 8 + (size_t)(m + 1) * 4 + 64; }
 int persist_max_cpw() { return PERSIST_MAX_CPW; }
-int persist_msg_words(int m_cap) { return 2 * (PMSG_HDR + m_cap + 1); }
-int launch_persist(Ctl *d_ctl, unsigned long long *cand, unsigned long long *msg, int *abort_flag, int m, int cpw, int nw, int msg_stride,
-                   int max_steps, hipStream_t s) {
+int persist_slot_words(int m_cap) { return (PMSG_HDR + m_cap + 1 + 31) / 32 * 32; }
+int launch_persist(Ctl *d_ctl, unsigned long long *head, unsigned long long *slot, int *abort_flag, unsigned long long *dbg, int m, int cpw, int nw,
+                   int slot_stride, int max_steps, int head_stride, hipStream_t s) {
   static size_t attr_bytes = 0;
   const size_t lds = persist_lds_bytes(m, cpw);
   if (lds > attr_bytes) {
@@ -1910,8 +1944,9 @@ int launch_persist(Ctl *d_ctl, unsigned long long *cand, unsigned long long *msg
     attr_bytes = lds;
   }
   PersistArgs a;
-  a.ctl = d_ctl; a.cand = cand; a.msg = msg; a.abort_flag = abort_flag;
-  a.cpw = cpw; a.nw = nw; a.msg_stride = msg_stride; a.max_steps = max_steps;
+  a.ctl = d_ctl; a.head = head; a.slot = slot; a.abort_flag = abort_flag; a.dbg = dbg;
+  a.cpw = cpw; a.nw = nw; a.slot_stride = slot_stride; a.max_steps = max_steps;
+  a.head_stride = head_stride;
   hipLaunchKernelGGL(k_persist, dim3((unsigned)nw), dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

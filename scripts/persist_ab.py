@@ -13,11 +13,11 @@ from mvolps_amd import synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 api = mvolps_amd.api()
 mvolps_amd.require_device()
-for (m, n) in ((256, 512), (512, 1024), (1024, 2048), (1024, 4096)):
+for (m, n) in [tuple(int(v) for v in s.split("x")) for s in os.environ.get("AB_SIZES", "256x512,512x1024,1024x2048,1024x4096").split(",")]:
     A, b, c = synth.dense_lp(m, n, 12345)
     row = {"m": m, "n": n}
     objs = []
-    for mode in (0, 1, 0, 1):
+    for mode in (0, 2, 0, 2):  # 2 = resident-tableau path with its size cap lifted
         api.set_persist(mode)
         P = api.create()
         P.load_dense(A, b, c)
@@ -37,5 +37,11 @@ for (m, n) in ((256, 512), (512, 1024), (1024, 2048), (1024, 4096)):
     api.persist_stats(C.byref(la), C.byref(ab))
     row["same_bits"] = len(set(objs)) == 1 and row["persist_full"] == row["two_kernel_full"]
     row["launches"], row["aborts"] = la.value, ab.value
+    cyc = (C.c_ulonglong * 8)()
+    api.persist_cycles(cyc)
+    tot = list(cyc)
+    row["cycles_per_pivot_cumulative"] = {k: tot[i] / max(1, tot[4]) for i, k in enumerate(("propose", "gather", "read", "apply"))}
+    row["cycles_per_pivot_cumulative"]["sweeps"] = tot[5] / max(1, tot[4])
+    row["cycles_per_pivot_cumulative"]["first_sweep"] = tot[6] / max(1, tot[4])
     row["frac_hbm_roofline_persist"] = 16 * (m + 1) * (n + 1) / (row["persist_us_per_pivot"] * 1e-6) / 8e12
     print(json.dumps(row), flush=True)

@@ -136,3 +136,18 @@ def test_children_stay_with_their_parents_rank(orc, tmp_path):
     assert so["children"] == sr["children"] > 4000
     assert abs(sr["migrated"] / sr["children"] - 0.5) < 0.1
     assert so["migrated"] < 0.25 * sr["migrated"], (so, sr)
+
+
+def test_world2_on_the_config5_instance(orc, tmp_path):
+    """BASELINE config 5 on two ranks (gloo, oracle engine per rank): the first 200 nodes of the calibrated 512x1024
+    tree equal the oracle's serial record in tests/golden/config5.json."""
+    import os
+
+    from mvolps_amd import treedigest
+
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5.json")))
+    case = (fx["m"], fx["n"], fx["seed"], fx["U"], fx["cap"])
+    res = dist_helpers.run_world(2, case, dict(quirks=0, max_nodes=200, per_rank=8), str(tmp_path))
+    assert_same(res[0], res[1])
+    assert treedigest.digest(res[0]) == fx["prefix"]["200"]["sha256"]
+    assert res[0]["total_pivots"] == fx["prefix"]["200"]["pivots"]

@@ -167,21 +167,49 @@ def test_five_thousand_node_tree_three_ways(gpu, orc):
     assert abs(ref["best_lower"] - 210.0) <= 1e-9 * 210  # HiGHS milp optimum (tests/golden: ilp_16x32_s5)
 
 
-def test_config5_instance_digest(gpu):
-    """BASELINE config 5 instance (tests/golden/config5.json, written by scripts/config5.py): the first 3000
-    nodes of the 512x1024 FIFO tree through the windowed driver reproduce the recorded event-stream digest
-    (recorded from the node-at-a-time driver, whose first nodes are checked against the oracle above)."""
-    import sys
-
+def _config5():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "scripts"))
-    import config5
-
     fx = json.load(open(os.path.join(root, "tests", "golden", "config5.json")))
-    A, b, c, U = synth.dense_ilp(fx["m"], fx["n"], fx["seed"], int(fx["U"]))
-    r = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=0, max_nodes=3000, window=32)
-    assert r["count"] == fx["prefix_3000"]["nodes"] and r["total_pivots"] == fx["prefix_3000"]["pivots"]
-    assert config5.digest(r) == fx["prefix_3000"]["sha256"]
+    A, b, c, U = synth.dense_ilp(fx["m"], fx["n"], fx["seed"], fx["U"], fx["cap"])
+    return fx, (A, b, c, U)
+
+
+def _matches(r, rec):
+    from mvolps_amd import treedigest
+
+    assert r["count"] == rec["count"] and r["n_nodes"] == rec["n_nodes"] and r["total_pivots"] == rec["pivots"]
+    assert r["hit_limit"] == rec["hit_limit"] and r["has_incumbent"] == rec["has_incumbent"]
+    assert treedigest.digest(r) == rec["sha256"]
+
+
+def test_config5_full_tree_equals_the_oracle_record(gpu):
+    """BASELINE config 5: the calibrated 512x1024 ILP (tests/golden/config5.json, written by tests/golden/make_config5.py
+    from the ORACLE alone).  Its FIFO tree finishes after ~15.7k nodes with the incumbent replaced several times
+    (bs.cpp:172-174) and bound pruning at work (bs.cpp:210).  The windowed GPU driver reproduces the oracle's event
+    stream, prune labels and parents (sha256 over all of them), node for node, and the incumbent itself."""
+    fx, (A, b, c, U) = _config5()
+    rec = fx["full"]
+    assert not rec["hit_limit"] and rec["incumbent_updates"] >= 2 and rec["prune_counts"]["3"] > 0
+    r = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=0)
+    _matches(r, rec)
+    assert float(r["best_lower"]).hex() == rec["best_lower"] and r["incumbent_oid"] == rec["incumbent_oid"]
+    assert [(j + 1, v) for j, v in enumerate(r["x"]) if v != 0.0] == [tuple(t) for t in rec["x_nonzero"]]
+
+
+@pytest.mark.parametrize("window", [1, 32])
+def test_config5_prefix_other_drivers(gpu, window):
+    """The first 3000 nodes through the node-at-a-time driver and a 32-wide window: same digest as the oracle's."""
+    fx, (A, b, c, U) = _config5()
+    r = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=0, max_nodes=3000, window=window)
+    _matches(r, fx["prefix"]["3000"])
+
+
+def test_config5_bug_compatible_prefix(gpu):
+    """The same instance with bs.cpp's own bounds handling (GLP_UP / GLP_LO drop the opposite bound, bs.cpp:274,282):
+    infeasibility all but disappears and the tree no longer closes; first 1000 nodes against the oracle's record."""
+    fx, (A, b, c, U) = _config5()
+    r = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=1, max_nodes=1000)
+    _matches(r, fx["bugcompat_prefix"]["1000"])
 
 
 def test_repaired_gmi_cuts_on_gpu(gpu, orc):

@@ -134,3 +134,21 @@ def test_minimisation_ilp_repaired_mode_matches_milp(orc, case):
         assert rel(r["best_lower"], case["ilp_obj"]) <= RTOL
         x = np.array(r["x"])[-A.shape[1]:]
         assert np.all(A @ x >= 1 - 1e-7) and rel(float(c @ x), case["ilp_obj"]) <= RTOL
+
+
+def test_config5_fixture_is_the_oracles_record(orc):
+    """tests/golden/config5.json (BASELINE config 5) was written by tests/golden/make_config5.py from the oracle; a
+    prefix of its tree is re-derived here, so a fixture recorded from anything else would be caught on the CPU."""
+    import json
+    import os
+
+    from mvolps_amd import synth, treedigest
+    from oracle import oracle
+
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5.json")))
+    assert fx["source"].startswith("oracle") and not fx["full"]["hit_limit"]
+    assert 8000 <= fx["full"]["count"] <= 20000 and fx["full"]["incumbent_updates"] >= 2  # "~10k-node tree" that closes
+    A, b, c, U = synth.dense_ilp(fx["m"], fx["n"], fx["seed"], fx["U"], fx["cap"])
+    r = oracle.branch_and_bound(synth.load_ilp(orc, A, b, c, U), quirks=0, max_nodes=200)
+    rec = fx["prefix"]["200"]
+    assert treedigest.digest(r) == rec["sha256"] and r["total_pivots"] == rec["pivots"]
