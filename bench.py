@@ -150,7 +150,7 @@ def config5_fixture():
 def config5_instance():
     from mvolps_amd import synth
 
-    fx = config5_fixture() or {"m": 512, "n": 1024, "seed": 12345, "U": 3.0, "cap": 0.4, "reference_quirks": 0}
+    fx = config5_fixture() or {"m": 512, "n": 1024, "seed": 12345, "U": 1.0, "cap": 0.002, "reference_quirks": 0}
     A, b, c, U = synth.dense_ilp(fx["m"], fx["n"], fx["seed"], fx["U"], fx.get("cap", 0.4))
     return fx, (A, b, c, U)
 
@@ -188,50 +188,61 @@ def secondary(api, with_cpu=True):
     el = time.perf_counter() - t0
     out["dense_lp_1024x2048"] = {"pivots_per_s": 600 / el, "us_per_pivot": el / 600 * 1e6,
                                  "frac_of_hbm_roofline": 600 / el * bytes_per_pivot(1024, 2048) / 1e9 / HBM_PEAK_GBS}
-    # configs 3/5 shape: the calibrated config-5 ILP, FIFO B&B.  mvx_branchAndBound in window mode (64 node LPs share each
-    # launch) and the multi-rank coordinator on one rank (same tree, Python replay of the decisions)
-    fx, inst = config5_instance()
-    A, b, c, U = inst
-    q = int(fx.get("reference_quirks", 0))
+    # configs 3/5 shape: ILP 512x1024, FIFO B&B through mvx_branchAndBound in window mode (64 node LPs share each launch)
+    # and through the multi-rank coordinator on one rank (same tree, Python replay of the decisions).  Two instances:
+    # the WIDE one of round 1 (seed 12345, U = 3, cap = 0.4: the breadth-first tree doubles every level, thousands of
+    # open nodes -- throughput with every batch slot busy) and the CALIBRATED config-5 one (tests/golden/config5.json:
+    # cap = 0.002, a tree that closes after ~15.7k nodes but is only tens of nodes wide).
+    A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3, 0.4)
     nodes = 2000
-    bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=64)  # warm-up
+    bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=64)  # warm-up
     t0 = time.perf_counter()
-    r = bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=nodes)
+    r = bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes)
     el = time.perf_counter() - t0
-    want = (fx.get("prefix") or {}).get(str(nodes), {}).get("sha256")
-    out["bnb_ilp_512x1024"] = {"driver": "mvx_branchAndBound", "nodes": r["count"], "nodes_per_s": r["count"] / el,
-                               "pivots": r["total_pivots"], "pivots_per_s": r["total_pivots"] / el, "window": 64,
-                               "same_tree_as_oracle_fixture": (treedigest.digest(r) == want) if want else None}
+    out["bnb_ilp_512x1024"] = {"driver": "mvx_branchAndBound", "instance": "wide (cap 0.4, U 3)", "nodes": r["count"], "nodes_per_s": r["count"] / el,
+                               "pivots": r["total_pivots"], "pivots_per_s": r["total_pivots"] / el, "window": 64}
     eng = dist_bnb.HipNodeEngine(0)
     t0 = time.perf_counter()
-    r2 = dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=nodes, per_rank=64)
+    r2 = dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes, per_rank=64)
     el = time.perf_counter() - t0
     out["bnb_ilp_512x1024_coordinator"] = {"driver": "mvolps_amd.dist_bnb (1 rank)", "nodes": r2["count"], "nodes_per_s": r2["count"] / el,
-                                           "pivots": r2["total_pivots"], "same_tree": r2["prune"] == r["prune"], "per_rank": 64}
+                                           "pivots": r2["total_pivots"], "same_tree": treedigest.digest(r2) == treedigest.digest(r), "per_rank": 64}
     if with_cpu:
-        out["bnb_ilp_512x1024"]["cpu_baseline"] = bnb_cpu_baseline(inst, q)
+        out["bnb_ilp_512x1024"]["cpu_baseline"] = bnb_cpu_baseline((A, b, c, U), 0)
+    fx, inst = config5_instance()
+    if fx.get("full"):
+        A5, b5, c5, U5 = inst
+        q = int(fx.get("reference_quirks", 0))
+        t0 = time.perf_counter()
+        r5 = bnb.branch_and_bound(synth.load_ilp(api, A5, b5, c5, U5), quirks=q)
+        el = time.perf_counter() - t0
+        out["bnb_config5_tree"] = {"driver": "mvx_branchAndBound", "instance": "calibrated config 5 (cap %g, U %g): the whole tree" % (fx["cap"], fx["U"]),
+                                   "nodes": r5["count"], "nodes_per_s": r5["count"] / el, "pivots": r5["total_pivots"], "best": r5["best_lower"],
+                                   "incumbent_updates": treedigest.incumbent_updates(r5),
+                                   "same_tree_as_oracle_fixture": treedigest.digest(r5) == fx["full"]["sha256"]}
     return out
 
 
 def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes):
     """secondary.bnb_ilp_512x1024_dist (every rank calls this): the serial-equivalent node farm over the process
     group -- node LPs sharded over the ranks (bs.cpp:96-327), MAX all-reduces for the incumbent and the child bounds,
-    RCCL send/recv for the children that change ranks."""
+    RCCL send/recv for the children that change ranks.  Two instances, as in secondary(): the wide 512x1024 tree
+    (first `nodes` nodes; children dealt to their parent's rank, and round-robin as round 1 did for comparison) and the
+    calibrated config-5 tree run to its end and checked against the oracle's record."""
     import torch
 
-    from mvolps_amd import dist_bnb, synth, treedigest
+    from mvolps_amd import bnb, dist_bnb, synth, treedigest
 
-    fx, inst = config5_instance()
-    A, b, c, U = inst
-    q = int(fx.get("reference_quirks", 0))
     eng = dist_bnb.HipNodeEngine(dev_index, comm_device="cpu" if rehearsal else None)
-    dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=4 * world * 16, per_rank=16)  # warm-up
-    out = {}
-    for deal in ("owner", "roundrobin"):
+    A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3, 0.4)
+    dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=4 * world * 16, per_rank=16)  # warm-up
+
+    def timed(inst, quirks, max_nodes, deal):
+        Ai, bi, ci, Ui = inst
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        r = dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=q, max_nodes=nodes, per_rank=64, deal=deal)
+        r = dist_bnb.branch_and_bound(eng, synth.load_ilp(api, Ai, bi, ci, Ui), quirks=quirks, max_nodes=max_nodes, per_rank=64, deal=deal)
         dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -239,18 +250,31 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         st = r["dist"]
-        want = (fx.get("prefix") or {}).get(str(nodes), {}).get("sha256")
-        out[deal] = {"nodes": r["count"], "nodes_per_s": r["count"] / el, "pivots": r["total_pivots"], "seconds": el,
-                     "children": st["children"], "migrated_images": st["migrated"], "migrated_share": st["migrated"] / max(1, st["children"]),
-                     "migrated_bytes_per_node": st["migrated_bytes"] / max(1, r["count"]), "rounds": st["rounds"],
-                     "same_tree_as_oracle_fixture": (treedigest.digest(r) == want) if want else None}
-    res = out["owner"]
+        return r, {"nodes": r["count"], "nodes_per_s": r["count"] / el, "pivots": r["total_pivots"], "seconds": el, "children": st["children"],
+                   "migrated_images": st["migrated"], "migrated_share": st["migrated"] / max(1, st["children"]),
+                   "migrated_bytes_per_node": st["migrated_bytes"] / max(1, r["count"]), "rounds": st["rounds"]}
+
+    r_own, own = timed((A, b, c, U), 0, nodes, "owner")
+    r_rr, rr = timed((A, b, c, U), 0, nodes, "roundrobin")
+    res = dict(own)
+    res["instance"] = "wide (cap 0.4, U 3), first %d nodes" % nodes
+    res["same_tree_both_dealings"] = treedigest.digest(r_own) == treedigest.digest(r_rr)
+    if rank == 0:  # the single-GPU driver on the same prefix, for the tree only
+        r1 = bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes)
+        res["same_tree_as_single_gpu_driver"] = treedigest.digest(r1) == treedigest.digest(r_own)
+    res["roundrobin_dealing"] = {k: rr[k] for k in ("nodes_per_s", "migrated_images", "migrated_share", "migrated_bytes_per_node")}
+    fx, inst5 = config5_instance()
+    if fx.get("full"):
+        r5, c5 = timed(inst5, int(fx.get("reference_quirks", 0)), 0, "owner")
+        c5["instance"] = "calibrated config 5 (cap %g, U %g): the whole tree" % (fx["cap"], fx["U"])
+        c5["same_tree_as_oracle_fixture"] = treedigest.digest(r5) == fx["full"]["sha256"]
+        c5["best"] = r5["best_lower"]
+        res["config5_tree"] = c5
     res["driver"] = "mvolps_amd.dist_bnb"
     res["ranks"] = world
     res["per_rank"] = 64
     res["collective"] = {"backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL over xGMI)", "ranks": world,
                          "ops_per_round": "2 MAX all-reduces + send/recv of migrated node images"}
-    res["roundrobin_dealing"] = {k: out["roundrobin"][k] for k in ("nodes_per_s", "migrated_images", "migrated_share", "migrated_bytes_per_node")}
     return res
 
 
@@ -283,7 +307,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements of configs 2 and 3/5")
     ap.add_argument("--profile-steps", type=int, default=200, help="extra pivots timed per-kernel with HIP events")
-    ap.add_argument("--bnb-nodes", type=int, default=3000, help="nodes of the config-5 tree the distributed B&B leg runs (N>1)")
+    ap.add_argument("--bnb-nodes", type=int, default=3000, help="nodes of the wide 512x1024 tree the distributed B&B leg runs (N>1)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

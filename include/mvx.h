@@ -185,7 +185,8 @@ void mvx_set_tuning(int tr, int hot, int nt);
 /* Tableau refresh.  A dense Gauss-Jordan tableau carries the rounding of every pivot it has been through (GLPK
    refactorises its basis behind glp_simplex, bs.cpp:117).  A solve that ends OPTIMAL on a handle with at least
    `check_every` pivots since the last look (default 1024; clones inherit the count) computes the residual of the row
-   equations, max_i |sum_j a_ij x_j - x_Ri| / (1 + |x_Ri|) (mvx_row_residual); above `tol` (default 1e-9) the tableau
+   equations, max_i |sum_j a_ij x_j - x_Ri| / (1 + |x_Ri|), over 32 rows picked from the pivot count (mvx_row_residual
+   gives it over all rows); above `tol` (default 1e-9) the tableau
    is rebuilt from the model for the same basis -- slack tableau with the non-basic variables on their bounds, then
    the basic structural variables pivoted back in by ascending variable number, each on the row of largest |entry|
    among the rows whose auxiliary has to leave -- and the simplex carries on.  Same rule, same arithmetic, in the

@@ -907,11 +907,14 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       R->after1.assign(nk, 0);
       R->repiv.assign(nk, -1);
       R->obj1.assign(nk, 0.0);
-      auto work = [api, R, nk]() {
-        api->simplex_batch(R->kids.data(), (int)nk, nullptr, nullptr);
+      // the children go through the engine's batch entry in two halves on two threads: the host side of one batch
+      // (control-block uploads, polls, result mirrors) overlaps the kernels of the other
+      auto solve_range = [api, R](size_t lo, size_t hi) {
+        if (hi <= lo) return;
+        api->simplex_batch(R->kids.data() + lo, (int)(hi - lo), nullptr, nullptr);
         std::vector<void *> again;
         std::vector<size_t> idx;
-        for (size_t k = 0; k < nk; k++) {
+        for (size_t k = lo; k < hi; k++) {
           R->after1[k] = api->get_it_cnt(R->kids[k]);
           R->obj1[k] = api->get_obj_val(R->kids[k]);
           const int st1 = api->get_status(R->kids[k]);
@@ -924,6 +927,17 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
           api->simplex_batch(again.data(), (int)again.size(), nullptr, nullptr);
           for (size_t t = 0; t < idx.size(); t++) R->repiv[idx[t]] = api->get_it_cnt(again[t]) - R->after1[idx[t]];
         }
+      };
+      const bool two = nk >= 32 && !std::getenv("MVX_BNB_ONE_WORKER");
+      auto work = [solve_range, nk, two]() {
+        if (!two) {
+          solve_range(0, nk);
+          return;
+        }
+        const size_t half = (nk / 2 + 1) & ~(size_t)1; // siblings stay together
+        auto other = std::async(std::launch::async, solve_range, half, nk);
+        solve_range(0, half);
+        other.get();
       };
       if (prm.window > 1 && !std::getenv("MVX_BNB_SYNC")) pend.fut = std::async(std::launch::async, work);
       else work();

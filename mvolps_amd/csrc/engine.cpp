@@ -139,6 +139,7 @@ struct Context {
   // context of their own: the batch call may come from the B&B driver's worker thread while the calling thread
   // uses `main` for cut rows and solution queries
   SolveCtx aux;
+  std::mutex aux_mu; // one single-handle solve at a time on `aux` (two batch calls may run on two threads)
   SlabCache slabs;
   // clones recorded by engine_copy and not yet launched (main_mu held): a round of B&B branchings makes one clone per
   // branching with only host-side work in between, so they leave as ONE k_copy_many launch when the next entry point
@@ -1067,13 +1068,15 @@ static int solve_once(mvx_prob *P, const mvx_smcp *parm, bool aux) {
   if (!job_prepare(J, P, parm)) return J.rc;
   Context &c = ctx();
   HIPCHECK(hipSetDevice(c.dev)); // the current device is per host thread (the B&B driver solves from a worker thread)
+  std::unique_lock<std::recursive_mutex> main_lock(c.main_mu);
+  flush_copies(c);
+  if (aux) main_lock.unlock();
+  std::unique_lock<std::mutex> aux_lock(c.aux_mu, std::defer_lock);
+  if (aux) aux_lock.lock();
   if (aux && !c.aux_ready) {
     init_solve_ctx(c.aux);
     c.aux_ready = true;
   }
-  std::unique_lock<std::recursive_mutex> main_lock(c.main_mu);
-  flush_copies(c);
-  if (aux) main_lock.unlock();
   J.sc = aux ? &c.aux : &c.main;
   job_begin(c, J);
   for (;;) {
@@ -1092,7 +1095,12 @@ void set_refresh(int check_every, double tol) {
   g_refresh_tol = tol >= 0.0 ? tol : 1e-9;
 }
 
-double row_residual(const mvx_prob *P) {
+constexpr int REFRESH_SAMPLE_ROWS = 32; // rows the look that decides on a refresh reads (oracle: REFRESH_SAMPLE_ROWS)
+static double row_residual_sample(const mvx_prob *P, int rows);
+double row_residual(const mvx_prob *P) { return row_residual_sample(P, 0); }
+
+// residual over `rows` rows picked from the pivot count (rows <= 0 or >= m: every row)
+static double row_residual_sample(const mvx_prob *P, int rows) {
   if (!P->valid) return 0.0;
   refresh_solution(P);
   const int m = P->m, n = P->n;
@@ -1106,7 +1114,10 @@ double row_residual(const mvx_prob *P) {
   std::vector<double> x((size_t)n + 1, 0.0);
   for (int j = 1; j <= n; j++) x[(size_t)j] = value(m + j);
   double worst = 0.0;
-  for (int i = 1; i <= m; i++) {
+  const bool all = rows <= 0 || rows >= m;
+  const int cnt = all ? m : rows;
+  for (int k = 0; k < cnt; k++) {
+    const int i = all ? k + 1 : 1 + (int)(((unsigned)P->it_cnt * 2654435761u + (unsigned)k * 0x9E3779B1u) % (unsigned)m);
     const double *a = P->A[(size_t)i]->data();
     double acc = 0.0;
     for (int j = 1; j <= n; j++) acc = acc + a[j] * x[(size_t)j];
@@ -1149,7 +1160,7 @@ static int after_solve(mvx_prob *P, const mvx_smcp *parm, int rc, int pivots) {
   P->piv_since_check += pivots;
   if (rc == 0 && P->status == MVX_OPT && P->piv_since_check >= g_check_every) {
     P->piv_since_check = 0;
-    if (row_residual(P) > g_refresh_tol && refresh_tableau(P)) {
+    if (row_residual_sample(P, REFRESH_SAMPLE_ROWS) > g_refresh_tol && refresh_tableau(P)) {
       const int before = P->it_cnt;
       rc = solve_once(P, parm, true); // the pivot limit of the call, if any, applies to this leg afresh
       P->piv_since_check += P->it_cnt - before;
@@ -1190,10 +1201,15 @@ struct BatchCtx {
   unsigned char *d_stage = nullptr, *h_stage = nullptr; // one staging area per JOB
   size_t stage_stride = 0;
 };
-static BatchCtx g_batch;
-static std::mutex g_batch_mu; // one batched solve at a time
+// Two batch contexts (stream, slot control blocks, scratch, staging): two host threads can each drive a batched solve
+// at the same time -- the B&B driver splits a round's children over two workers, so that the host side of one batch
+// (uploads, polls, result mirrors) overlaps the kernels of the other.
+constexpr int N_BATCH_CTX = 2;
+static BatchCtx g_batch[N_BATCH_CTX];
+static std::mutex g_batch_mu[N_BATCH_CTX];
 static void sync_batch_stream() {
-  if (g_batch.stream) HIPCHECK(hipStreamSynchronize(g_batch.stream));
+  for (int k = 0; k < N_BATCH_CTX; k++)
+    if (g_batch[k].stream) HIPCHECK(hipStreamSynchronize(g_batch[k].stream));
 }
 static int g_batch_slots = 64;
 
@@ -1345,8 +1361,18 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     return 0;
   }
   if (pending.empty()) return 0;
-  std::lock_guard<std::mutex> batch_lock(g_batch_mu);
-  BatchCtx &bc = g_batch;
+  // whichever batch context is free (the first, when both are)
+  std::unique_lock<std::mutex> batch_lock(g_batch_mu[0], std::try_to_lock);
+  int which = 0;
+  if (!batch_lock.owns_lock()) {
+    batch_lock = std::unique_lock<std::mutex>(g_batch_mu[1], std::try_to_lock);
+    which = 1;
+    if (!batch_lock.owns_lock()) {
+      batch_lock = std::unique_lock<std::mutex>(g_batch_mu[0]);
+      which = 0;
+    }
+  }
+  BatchCtx &bc = g_batch[which];
   const int njobs = (int)pending.size();
   const int K = std::min(njobs, g_batch_slots);
   ensure_batch(bc, K, njobs, m_cap, ld);

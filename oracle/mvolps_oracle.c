@@ -945,7 +945,7 @@ static int dual_simplex(orc_prob *P, ctl_t *ctl) {
    A dense tableau carries the rounding of every pivot it has been through (GLPK refactorises its basis behind
    glp_simplex; a Gauss-Jordan tableau has nothing to refactorise).  Rule, identical in the HIP engine: a solve that
    ends OPTIMAL on a handle with at least `check_every` pivots since the last look computes the residual of the row
-   equations, max_i |sum_j A_ij x_j - x_Ri| / (1 + |x_Ri|); above `tol` the tableau is REBUILT from the model for the
+   equations, max_i |sum_j A_ij x_j - x_Ri| / (1 + |x_Ri|), over 32 rows picked from the pivot count; above `tol` the tableau is REBUILT from the model for the
    same basis -- slack tableau with every non-basic variable on the bound it sits at, then the basic structural
    variables pivoted back in, in ascending variable number, each on the row of largest |entry| (lowest row on ties)
    among the rows whose auxiliary has to leave -- and the simplex carries on from there. */
@@ -966,7 +966,13 @@ static double var_value(const orc_prob *P, const int *pos, int k) {
   return nb_value(P->nflag[-q], lb, ub);
 }
 
-double orc_row_residual(const orc_prob *P) {
+/* residual over `rows` rows picked from the pivot count (rows <= 0 or >= m: every row) */
+static double row_residual_sample(const orc_prob *P, int rows);
+double orc_row_residual(const orc_prob *P) { return row_residual_sample(P, 0); }
+
+#define REFRESH_SAMPLE_ROWS 32 /* the look that decides on a refresh reads this many rows, not all m (one look costs
+                                  O(rows * n) on the host; a lineage of B&B nodes takes one every check_every pivots) */
+static double row_residual_sample(const orc_prob *P, int rows) {
   if (!P->valid) return 0.0;
   int m = P->m, n = P->n;
   int *pos = (int *)xcalloc((size_t)m + n + 1, sizeof(int));
@@ -975,7 +981,10 @@ double orc_row_residual(const orc_prob *P) {
   double *x = (double *)xcalloc((size_t)n + 1, sizeof(double));
   for (int j = 1; j <= n; j++) x[j] = var_value(P, pos, m + j);
   double worst = 0.0;
-  for (int i = 1; i <= m; i++) {
+  int all = rows <= 0 || rows >= m;
+  int cnt = all ? m : rows;
+  for (int k = 0; k < cnt; k++) {
+    int i = all ? k + 1 : 1 + (int)(((unsigned)P->it_cnt * 2654435761u + (unsigned)k * 0x9E3779B1u) % (unsigned)m);
     double acc = 0.0;
     const double *a = P->A[i];
     for (int j = 1; j <= n; j++) acc = acc + a[j] * x[j];
@@ -1045,7 +1054,7 @@ int orc_simplex(orc_prob *P, const orc_smcp *parm) {
   P->piv_since_check += P->it_cnt - before;
   if (rc == 0 && P->status == ORC_OPT && P->piv_since_check >= g_check_every) {
     P->piv_since_check = 0;
-    if (orc_row_residual(P) > g_refresh_tol) {
+    if (row_residual_sample(P, REFRESH_SAMPLE_ROWS) > g_refresh_tol) {
       refresh_tableau(P);
       before = P->it_cnt;
       rc = simplex_once(P, parm); /* the pivot limit of the call, if any, applies to this leg afresh */
