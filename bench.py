@@ -396,10 +396,11 @@ def main():
     device_ms = state["device_ms"]
 
     # max over ranks
-    t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    el_max = el
     if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el_max = float(t.item())
+        el_max = float(t.item())
 
     # per-kernel pass: HIP events around every k_fb launch, on the engine's own stream.  It runs on the
     # same handle right after the timed region (the next pivots of the same LP) rather than inside it:

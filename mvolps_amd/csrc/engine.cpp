@@ -1194,6 +1194,7 @@ struct BatchCtx {
   hipStream_t stream = nullptr;
   Ctl *d_ctl = nullptr, *h_ctl = nullptr;   // slot control blocks (host copy: the idle pattern)
   Ctl *d_jobs = nullptr, *h_jobs = nullptr; // job control blocks
+  Ctl *h_fill = nullptr;                    // slot control blocks read back for the tail compaction
   SlotScratch *d_sp = nullptr, *h_sp = nullptr;
   int *d_cnt = nullptr, *h_cnt = nullptr; // [0] next job, [1] finished jobs
   unsigned char *scratch = nullptr;
@@ -1221,6 +1222,7 @@ static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
   if (bc.h_ctl) HIPCHECK(hipHostFree(bc.h_ctl));
   if (bc.d_jobs) HIPCHECK(hipFree(bc.d_jobs));
   if (bc.h_jobs) HIPCHECK(hipHostFree(bc.h_jobs));
+  if (bc.h_fill) HIPCHECK(hipHostFree(bc.h_fill));
   if (bc.d_sp) HIPCHECK(hipFree(bc.d_sp));
   if (bc.h_sp) HIPCHECK(hipHostFree(bc.h_sp));
   if (bc.d_cnt) HIPCHECK(hipFree(bc.d_cnt));
@@ -1236,6 +1238,7 @@ static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
   HIPCHECK(hipHostMalloc((void **)&bc.h_ctl, sizeof(Ctl) * bc.slots));
   HIPCHECK(hipMalloc((void **)&bc.d_jobs, sizeof(Ctl) * bc.jobs));
   HIPCHECK(hipHostMalloc((void **)&bc.h_jobs, sizeof(Ctl) * bc.jobs));
+  HIPCHECK(hipHostMalloc((void **)&bc.h_fill, sizeof(Ctl) * bc.slots));
   HIPCHECK(hipMalloc((void **)&bc.d_sp, sizeof(SlotScratch) * bc.slots));
   HIPCHECK(hipHostMalloc((void **)&bc.h_sp, sizeof(SlotScratch) * bc.slots));
   HIPCHECK(hipMalloc((void **)&bc.d_cnt, sizeof(int) * 4));
@@ -1392,14 +1395,32 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   q.count = njobs;
   // queue-ahead depth per poll: the slots refill themselves, so a poll only has to notice the end
   int depth = njobs <= 2 ? 8 : 16;
+  int Kact = K; // slots launched: all of them while the queue has work, the occupied ones once it is drained
+  int next_seen = 0; // the queue's hand-out counter as of the last poll
   for (;;) {
     for (int d = 0; d < depth; d++) {
-      launch_select_queue(bc.d_ctl, q, bc.stream, K);
-      launch_update(bc.d_ctl, m_max, n_max, bc.stream, K);
+      launch_select_queue(bc.d_ctl, q, bc.stream, Kact);
+      launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact);
     }
     HIPCHECK(hipMemcpyAsync(bc.h_cnt + 2, bc.d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, bc.stream));
+    const bool drained_before = next_seen >= njobs; // as of the previous poll: no slot can pull a job any more
+    if (drained_before && Kact > 1)
+      HIPCHECK(hipMemcpyAsync(bc.h_fill, bc.d_ctl, sizeof(Ctl) * (size_t)Kact, hipMemcpyDeviceToHost, bc.stream));
     HIPCHECK(hipStreamSynchronize(bc.stream));
+    next_seen = bc.h_cnt[2];
     if (bc.h_cnt[3] >= njobs) break;
+    if (drained_before && Kact > 1) {
+      // Tail of the batch: the queue is empty and the slots finish one by one.  An idle slot of a launch still costs
+      // its share of workgroups that start only to leave (512x1024: 132 per slot), so the control blocks that still
+      // hold a job move to the front and the launches shrink.  Their pointers keep addressing their own scratch.
+      int w = 0;
+      for (int k = 0; k < Kact; k++) {
+        if (bc.h_fill[k].job < 0) continue;
+        if (k != w) HIPCHECK(hipMemcpyAsync(&bc.d_ctl[w], &bc.d_ctl[k], sizeof(Ctl), hipMemcpyDeviceToDevice, bc.stream));
+        w++;
+      }
+      if (w >= 1 && w < Kact) Kact = w;
+    }
     depth = std::min(depth * 2, 32);
   }
   HIPCHECK(hipMemcpyAsync(bc.h_stage, bc.d_stage, bc.stage_stride * (size_t)njobs, hipMemcpyDeviceToHost, bc.stream));

@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): basis indices and statuses bit-exact; tableau en
 objective are compared BITWISE as well (np.array_equal), which is stronger than the 1e-9
 relative tolerance asked for -- both sides run the same fma/div sequence.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -496,3 +498,33 @@ def test_batch_with_few_slots_refills_and_compacts(gpu, orc, slots):
             assert_same_state(kg, ko, "batched child, %d slots" % slots)
     finally:
         gpu.set_batch_slots(64)
+
+
+def test_glpk_default_tolerances_behind_null_parameters(gpu, orc):
+    """mvx_set_default_tolerances(1e-7, 1e-7, 1e-9): GLPK's own defaults [GLPK-recalled] behind every NULL-parameter
+    solve -- all MVOLPS ever makes (bs.cpp:117,279,287).  Oracle and device take the same switch and stay bit-identical,
+    LP and branch-and-bound alike."""
+    from mvolps_amd import bnb
+    from oracle import oracle
+
+    try:
+        for a in (gpu, orc):
+            a.set_default_tolerances(1e-7, 1e-7, 1e-9)
+        parm = capi.Smcp()
+        gpu.init_smcp(C.byref(parm))
+        assert (parm.tol_bnd, parm.tol_dj, parm.tol_piv) == (1e-7, 1e-7, 1e-9)
+        A, b, c = synth.dense_lp(96, 160, 3)
+        g, o = gpu.create(), orc.create()
+        for P in (g, o):
+            P.load_dense(A, b, c)
+            assert P.simplex() == 0
+        assert g.it_cnt == o.it_cnt and np.array_equal(g.tableau(), o.tableau())
+        A, b, c, U = synth.dense_ilp(10, 20, 4, 3)
+        for quirks in (1, 0):
+            ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=quirks, max_nodes=300)
+            got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), quirks=quirks, max_nodes=300)
+            for k in ("events", "prune", "parent", "node_bound", "total_pivots", "x"):
+                assert got[k] == ref[k], (quirks, k)
+    finally:
+        for a in (gpu, orc):
+            a.set_default_tolerances(1e-9, 1e-9, 1e-9)
