@@ -14,6 +14,7 @@
 #include <future>
 #include <limits>
 #include <memory>
+#include <unordered_map>
 #include <unordered_set>
 #include <utility>
 #include <vector>
@@ -705,8 +706,12 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     std::future<void> fut;
     bool active = false;
   };
-  Round pend;
-  std::unordered_set<const void *> inflight;
+  // Rounds whose children are still being solved, oldest first.  Up to `depth` of them: while the slowest children of
+  // one round finish (few batch slots busy), the next round's batch is already running on another batch context.
+  std::deque<std::unique_ptr<Round>> flight;
+  std::unordered_map<const void *, const Round *> inflight; // child handle -> the round that is solving it
+  size_t depth = 2;
+  if (const char *e = std::getenv("MVX_BNB_DEPTH")) depth = (size_t)std::max(1, std::min(4, std::atoi(e)));
   CutPool pool(api); // persistent across nodes in bug-compatible mode (cut.h:15-23)
   const bool timing = std::getenv("MVX_BNB_TIMING") != nullptr;
   double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tWait = 0;
@@ -734,8 +739,20 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     }
     rec.sink = nullptr;
     for (auto &ne : R.node_events) rec.events.insert(rec.events.end(), ne.begin(), ne.end());
-    inflight.clear();
-    R = Round();
+    for (void *k : R.kids) inflight.erase(k);
+  };
+  // rounds finish in the order they were started: the event stream is the serial one
+  auto finalize_oldest = [&]() {
+    if (flight.empty()) return;
+    finalize(*flight.front());
+    flight.pop_front();
+  };
+  auto finalize_through = [&](const Round *upto) {
+    while (!flight.empty()) {
+      const bool last = flight.front().get() == upto;
+      finalize_oldest();
+      if (last) break;
+    }
   };
 
   while (!leafContainer.empty() && !stop) {
@@ -746,11 +763,10 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     double t0 = now();
     const size_t W = std::min(leafContainer.size(), (size_t)prm.window);
     // the window may reach into the children that are still being solved
-    for (size_t w = 0; w < W; w++)
-      if (inflight.count(leafContainer[w]->prob)) {
-        finalize(pend);
-        break;
-      }
+    for (size_t w = 0; w < W; w++) {
+      auto it = inflight.find(leafContainer[w]->prob);
+      if (it != inflight.end()) finalize_through(it->second);
+    }
     // A. solve the window (bs.cpp:114-117).  The reference copies the node's problem into the scratch
     // `a` and solves the copy; the node is discarded after this step either way, so its own clone is
     // solved in place here -- same state, one device-to-device clone fewer per node.  A node whose last
@@ -764,10 +780,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       const int st = api->get_status(a[w]);
       if (st != MVX_OPT) need.push_back(a[w]);
     }
-    if (!need.empty()) {
-      finalize(pend); // the engine runs one batch at a time
-      api->simplex_batch(need.data(), (int)need.size(), nullptr, nullptr);
-    }
+    if (!need.empty()) api->simplex_batch(need.data(), (int)need.size(), nullptr, nullptr); // none of them is in flight
     tA += now() - t0; t0 = now();
     // B. replay in queue order
     Round cur;
@@ -885,16 +898,17 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     // C. every child of this round is an independent LP (bs.cpp:279,287): one batched solve, on the worker
     // thread; then, for the children found infeasible (or unbounded), the re-solve bs.cpp:117 will ask for when they are
     // popped (it depends on nothing that happens in between), so that popping never has to solve.
-    finalize(pend); // one round in flight at a time; its events come before this round's
+    while (flight.size() >= depth) finalize_oldest(); // at most `depth` rounds in flight; events stay in round order
     for (auto &br : branches) {
       cur.kids.push_back(br.S2->prob);
       cur.kids.push_back(br.S3->prob);
     }
     cur.active = true;
-    pend = std::move(cur);
+    flight.push_back(std::make_unique<Round>(std::move(cur)));
+    Round &pend = *flight.back();
     if (!pend.kids.empty()) {
       Round *R = &pend;
-      for (void *k : R->kids) inflight.insert(k);
+      for (void *k : R->kids) inflight.emplace(k, R);
       const size_t nk = R->kids.size();
       R->after1.assign(nk, 0);
       R->repiv.assign(nk, -1);
@@ -936,7 +950,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     }
     leafContainer.erase(leafContainer.begin(), leafContainer.begin() + (long)processed);
   }
-  finalize(pend);
+  while (!flight.empty()) finalize_oldest();
   if (timing)
     std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f)  waiting for child solves %.1f ms\n", tA * 1e3,
                  tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tWait * 1e3);

@@ -1205,7 +1205,7 @@ struct BatchCtx {
 // Two batch contexts (stream, slot control blocks, scratch, staging): two host threads can each drive a batched solve
 // at the same time -- the B&B driver splits a round's children over two workers, so that the host side of one batch
 // (uploads, polls, result mirrors) overlaps the kernels of the other.
-constexpr int N_BATCH_CTX = 2;
+constexpr int N_BATCH_CTX = 4;
 static BatchCtx g_batch[N_BATCH_CTX];
 static std::mutex g_batch_mu[N_BATCH_CTX];
 static void sync_batch_stream() {
@@ -1364,16 +1364,16 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     return 0;
   }
   if (pending.empty()) return 0;
-  // whichever batch context is free (the first, when both are)
-  std::unique_lock<std::mutex> batch_lock(g_batch_mu[0], std::try_to_lock);
-  int which = 0;
-  if (!batch_lock.owns_lock()) {
-    batch_lock = std::unique_lock<std::mutex>(g_batch_mu[1], std::try_to_lock);
-    which = 1;
-    if (!batch_lock.owns_lock()) {
-      batch_lock = std::unique_lock<std::mutex>(g_batch_mu[0]);
-      which = 0;
-    }
+  // whichever batch context is free; all busy: wait for the first
+  std::unique_lock<std::mutex> batch_lock;
+  int which = -1;
+  for (int k = 0; k < N_BATCH_CTX && which < 0; k++) {
+    batch_lock = std::unique_lock<std::mutex>(g_batch_mu[k], std::try_to_lock);
+    if (batch_lock.owns_lock()) which = k;
+  }
+  if (which < 0) {
+    batch_lock = std::unique_lock<std::mutex>(g_batch_mu[0]);
+    which = 0;
   }
   BatchCtx &bc = g_batch[which];
   const int njobs = (int)pending.size();
