@@ -50,6 +50,9 @@ int fused_nrb_max(int m);
 void launch_fboot(Ctl *, int n, hipStream_t);
 void launch_fa(Ctl *, int n, hipStream_t);
 void launch_fb(Ctl *, int m, int n, hipStream_t);
+void launch_dboot(Ctl *, int n, hipStream_t);
+void launch_da(Ctl *, int n, hipStream_t);
+void launch_db(Ctl *, int m, int n, hipStream_t);
 void launch_select(Ctl *, hipStream_t, int slots = 1);
 void launch_select_queue(Ctl *, const BatchQueue &q, hipStream_t, int slots);
 void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1);
@@ -88,7 +91,7 @@ struct SolveCtx {
   double *d_colq = nullptr, *d_srow = nullptr, *d_cost1 = nullptr, *d_wts = nullptr, *d_part = nullptr, *d_rcbase = nullptr;
   int *d_gflag = nullptr;
   double *d_colqx[2] = {nullptr, nullptr}, *d_betac[2] = {nullptr, nullptr};
-  double *d_dw = nullptr; // dual devex weights by row
+  double *d_dw = nullptr, *d_dw2 = nullptr; // dual devex weights by row, two sets (fused dual path ping-pong)
   int *d_p1list = nullptr; // phase 1: rows whose infeasibility sign changed
   int *d_tflag = nullptr;  // tableau refresh: target non-basic status by variable number
   double *d_pw[2] = {nullptr, nullptr}; // primal devex weights by column, two sets (fused path ping-pong)
@@ -254,7 +257,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_pp0 = carve((size_t)fused_npb(l) * sizeof(Cand)), o_pp1 = carve((size_t)fused_npb(l) * sizeof(Cand));
   size_t o_rp = carve((size_t)fused_nrb_max(mc) * sizeof(Cand));
   size_t o_olb = carve((size_t)(mc + l + 1) * 8), o_oub = carve((size_t)(mc + l + 1) * 8);
-  size_t o_dw = carve((size_t)(mc + 1) * 8);
+  size_t o_dw = carve((size_t)(mc + 1) * 8), o_dw2 = carve((size_t)(mc + 1) * 8);
   size_t o_p1l = carve((size_t)(mc + 2) * 4);
   size_t o_pw0 = carve((size_t)l * 8), o_pw1 = carve((size_t)l * 8);
   size_t o_tf = carve((size_t)(mc + l + 1) * 4);
@@ -278,6 +281,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_olb = (double *)(b + o_olb);
   sc.d_oub = (double *)(b + o_oub);
   sc.d_dw = (double *)(b + o_dw);
+  sc.d_dw2 = (double *)(b + o_dw2);
   sc.d_p1list = (int *)(b + o_p1l);
   sc.d_pw[0] = (double *)(b + o_pw0);
   sc.d_pw[1] = (double *)(b + o_pw1);
@@ -531,6 +535,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->phase = PH_START; h->done = D_RUN; h->budget = -1;
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->olb = sc.d_olb; h->oub = sc.d_oub; h->dw = sc.d_dw;
+  h->dwx[0] = sc.d_dw; h->dwx[1] = sc.d_dw2;
   h->pw[0] = sc.d_pw[0]; h->pw[1] = sc.d_pw[1];
   h->p1_list = sc.d_p1list;
   h->colqx[0] = sc.d_colqx[0]; h->colqx[1] = sc.d_colqx[1];
@@ -731,9 +736,9 @@ static bool persist_plan(Context &c, const mvx_prob *P, PersistPlan *pl) {
 static bool ensure_persist(Context &c, SolveCtx &sc, const mvx_prob *P, const PersistPlan &pl) {
   const int words = persist_slot_words(P->m_cap);
   if (!sc.d_pabort) {
-    HIPCHECK(hipMalloc((void **)&sc.d_pabort, 256));
-    HIPCHECK(hipMemsetAsync(sc.d_pabort, 0, 256, sc.stream));
-    HIPCHECK(hipHostMalloc((void **)&sc.h_pabort, 256));
+    HIPCHECK(hipMalloc((void **)&sc.d_pabort, 1024));
+    HIPCHECK(hipMemsetAsync(sc.d_pabort, 0, 1024, sc.stream));
+    HIPCHECK(hipHostMalloc((void **)&sc.h_pabort, 1024));
     sc.h_pabort[0] = 0;
     HIPCHECK(hipMalloc((void **)&sc.d_pcand, (size_t)2 * 256 * PERSIST_HEAD_STRIDE_MAX * 8));
     HIPCHECK(hipMalloc((void **)&sc.d_pctl, sizeof(Ctl)));
@@ -771,6 +776,7 @@ struct SolveJob {
   int batch = 8, pb = 4;
   int done = D_RUN;
   bool try_fused = false;
+  bool try_dfused = false;    // dual phase on a large tableau: k_dboot / k_da / k_fb<DUAL>
   bool persist_queued = false; // this batch of launches contains a k_persist launch (its abort flag is copied back)
   int seen_steps = 0, seen_pivots = 0;
   size_t ev_used = 0;
@@ -788,7 +794,20 @@ static int pivot_budget(const mvx_prob *P, const mvx_smcp &parm) {
 static void stage_copy_async(SolveCtx &sc, const mvx_prob *P) {
   HIPCHECK(hipEventRecord(sc.ev_b, sc.stream)); // end of the device work queued so far (last_solve_ms)
   HIPCHECK(hipMemcpyAsync(sc.h_stage, sc.d_stage, stage_size(P->m_cap, P->ld), hipMemcpyDeviceToHost, sc.stream));
-  if (sc.d_pabort) HIPCHECK(hipMemcpyAsync(sc.h_pabort, sc.d_pabort, 128, hipMemcpyDeviceToHost, sc.stream)); // abort flag + phase cycle totals
+  if (sc.d_pabort) HIPCHECK(hipMemcpyAsync(sc.h_pabort, sc.d_pabort, 512, hipMemcpyDeviceToHost, sc.stream)); // abort flag + phase cycle totals
+}
+
+// The fused dual pipeline replaces k_select's four dependent stages (34 us at 4096x8192) by k_da (~8 us); below about
+// two million tableau entries the update itself is so short that the two extra bootstrap launches do not pay.
+static bool dual_fused_worth_it(const mvx_prob *P) {
+  static int mode = -1; // MVX_DUAL_FUSED=0 off, 1 size rule (default), 2 always
+  if (mode < 0) {
+    const char *e = std::getenv("MVX_DUAL_FUSED");
+    mode = e ? std::atoi(e) : 1;
+  }
+  if (mode == 0) return false;
+  if (mode >= 2) return true;
+  return (long)(P->m + 1) * (P->n + 1) >= 2000000;
 }
 
 static void job_begin(Context &c, SolveJob &J) {
@@ -805,6 +824,7 @@ static void job_begin(Context &c, SolveJob &J) {
   upload_ctl(sc);
   HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
+  J.try_dfused = P->hint_dual && dual_fused_worth_it(P);
   J.profiled = c.prof && J.sc == &c.main;
   // With a pivot limit the number of pivots wanted is known: queue them in one go (up to 256) instead of
   // growing the batch 8, 16, 32, ... -- every batch boundary costs a host round trip and a generic
@@ -877,6 +897,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
           if (head_stride < 4 || head_stride > PERSIST_HEAD_STRIDE_MAX) head_stride = 4;
         }
         HIPCHECK(hipMemsetAsync(sc.d_pcand, 0, (size_t)2 * pl.nw * head_stride * 8, sc.stream));
+        if (std::getenv("MVX_PERSIST_ZERO_SLOTS")) HIPCHECK(hipMemsetAsync(sc.d_pmsg, 0, (size_t)2 * 256 * sc.p_msg_words * 8, sc.stream));
         const int steps = 1 << 24; // the pivot limit is the control block's `budget`, which the kernel counts down
         if (launch_persist(sc.d_ctl, sc.d_pcand, sc.d_pmsg, sc.d_pabort, (unsigned long long *)(sc.d_pabort + 16), P->m, pl.cpw, pl.nw, sc.p_msg_words, steps, head_stride, sc.stream) == 0) {
           J.persist_queued = true;
@@ -895,6 +916,20 @@ static void job_enqueue(Context &c, SolveJob &J) {
           ev();
           launch_fb(sc.d_ctl, m_grid, n, sc.stream);
           ev();
+        }
+      }
+    } else if (J.try_dfused) {
+      // one generic step settles the phase (and restarts the dual devex weights when the phase has just been
+      // entered); if it is the dual simplex, the fused pair k_da / k_fb<DUAL> takes over, otherwise its launches
+      // return at once
+      launch_select(sc.d_ctl, sc.stream);
+      launch_update(sc.d_ctl, m_grid, n, sc.stream);
+      if (depth > 1) {
+        launch_dboot(sc.d_ctl, n, sc.stream);
+        launch_db(sc.d_ctl, m_grid, n, sc.stream);
+        for (int k = 0; k < depth - 1; k++) {
+          launch_da(sc.d_ctl, n, sc.stream);
+          launch_db(sc.d_ctl, m_grid, n, sc.stream);
         }
       }
     } else {
@@ -994,6 +1029,7 @@ static bool job_collect(Context &c, SolveJob &J) {
       J.mode = SolveJob::MAIN;
       J.batch = 8;
       J.try_fused = false;
+      J.try_dfused = false;
       return false;
     }
     J.done = snap.done;
@@ -1009,6 +1045,7 @@ static bool job_collect(Context &c, SolveJob &J) {
   J.done = snap.done;
   J.seen_pivots = snap.it_cnt;
   J.try_fused = (snap.phase == PH_PRIMAL2) && snap.stall < snap.stall_limit; // the fused path prices by Dantzig only
+  J.try_dfused = (snap.phase == PH_DUAL) && snap.stall < snap.stall_limit && dual_fused_worth_it(J.P);
   if (J.done == D_NEED_PHASE1) {
     snap.done = D_RUN;
     snap.phase = PH_PHASE1;
@@ -1982,10 +2019,10 @@ void persist_stats(long long *launches, long long *aborts) {
 }
 // cycle totals of workgroup 0 per phase since the context was created: propose, gather, read, apply, pivots
 void persist_cycles(unsigned long long *out5) {
-  for (int k = 0; k < 7; k++) out5[k] = 0;
+  for (int k = 0; k < 48; k++) out5[k] = 0;
   if (!g_ctx || !g_ctx->main.h_pabort) return;
   const unsigned long long *d = (const unsigned long long *)(g_ctx->main.h_pabort + 16);
-  for (int k = 0; k < 7; k++) out5[k] = d[k];
+  for (int k = 0; k < 48; k++) out5[k] = d[k];
 }
 void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }

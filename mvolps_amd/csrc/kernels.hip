@@ -119,7 +119,7 @@ __device__ __forceinline__ KC load_kc(const Ctl *c) {
   k.colq = c->colq; k.srow = c->srow;
   k.bvar = c->bvar; k.nvar = c->nvar;
   k.olb = c->olb; k.oub = c->oub;
-  k.dw = c->dw;
+  k.dw = c->dwx[c->curA & 1];
   k.pw = c->pw[c->curA & 1];
   k.bland = c->stall >= c->stall_limit;
   k.m = c->m; k.n = c->n; k.ld = c->ld;
@@ -176,8 +176,8 @@ __device__ Cand dev_price(const KC &k, const double *cost, double sgn, Cand *lds
 __device__ __forceinline__ bool ratio_row(double a, int sdir, double beta, double lb, double ub, int gi, double tp, int i,
                                           Cand &x) {
   const double aa = (sdir > 0) ? a : -a;
-  double t;
-  int up;
+  double t = 0.0;
+  int up = 0;
   if (aa > tp) {
     if (gi < 0) return false;
     if (gi > 0) {
@@ -215,7 +215,7 @@ __device__ Cand dev_primal_ratio(const KC &k, int q, int sdir, const int *g, Can
     const double a = k.T[(size_t)i * ld + q];
     k.colq[i] = a;
     if (i == 0) continue;
-    Cand x;
+    Cand x{0.0, 0.0, 0, 0};
     if (ratio_row(a, sdir, k.T[(size_t)i * ld], k.blb[i], k.bub[i], g ? g[i] : 0, tp, i, x)) {
       if (k.bland) x.k2 = -(double)k.bvar[i]; // tie-break among equal steps
       if (cand_better<1>(x, best)) best = x;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
     __syncthreads();
     if (TIDX == 0) {
       const SlotScratch sp = q.scratch[blockIdx.z];
-      c->colq = sp.colq; c->srow = sp.srow; c->olb = sp.olb; c->oub = sp.oub; c->dw = sp.dw;
+      c->colq = sp.colq; c->srow = sp.srow; c->olb = sp.olb; c->oub = sp.oub; c->dw = sp.dw; c->dwx[0] = c->dwx[1] = sp.dw;
       c->pw[0] = c->pw[1] = sp.pw;
       c->job = j;
     }
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
   const int j = (int)blockIdx.x * 256 + TIDX;
   Cand best{0.0, 0.0, 0, 0};
   if (j >= 1 && j <= c->n) {
-    Cand x;
+    Cand x{0.0, 0.0, 0, 0};
     if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, c->pw[a][j], x)) best = x;
   }
   best = block_best<0>(best, lds);
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
         // bound flip: tableau body and objective row unchanged; column q changes status
         const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
         if (act && j >= 1) {
-          Cand x;
+          Cand x{0.0, 0.0, 0, 0};
           pwn[j] = wj_; // weights unchanged by a flip; the other set becomes current with k_fb's curA flip
           if (price_col(j == q ? nf : fj_, sgn * dold_, tol, j, wj_, x)) best = x;
         }
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
           wn = cc > wj_ ? cc : wj_;
         }
         pwn[j] = wn;
-        Cand x;
+        Cand x{0.0, 0.0, 0, 0};
         if (price_col(j == q ? lf : fj_, sgn * dnew, tol, j, wn, x)) best = x;
       }
     }
@@ -1198,9 +1198,9 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
 // always has at least 32 spare rows behind row m (mvx::ROW_SPARE), so the last block streams
 // whole tiles too: spare rows are never read by anything else and are re-zeroed when a cut row
 // is appended (k_add_rows).
-template <int TR, int HOT, int NT>
+template <int TR, int HOT, int NT, int DUAL>
 __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
-  if (c->done != D_RUN || c->fstate != F_RUN) return;
+  if (c->done != D_RUN || c->fstate != (DUAL ? F_RUN_DUAL : F_RUN)) return;
   const int cur = c->curB, nxt = cur ^ 1;
   const int step = c->step;
   const int m = c->m, n = c->n, p = c->p, q = c->q;
@@ -1298,9 +1298,9 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   // next entering column (0 = none: k_fa will stop); reduced after the stream has been issued
   for (int k = (TIDX & 63) + 64; k < npb; k += 64) {
     Cand x = ppn[k];
-    if (cand_better<0>(x, ncv)) ncv = x;
+    if (cand_better<DUAL ? 1 : 0>(x, ncv)) ncv = x; // primal: best pricing score; dual: smallest dual ratio
   }
-  const Cand nc = wave_bcast_best<0>(ncv);
+  const Cand nc = wave_bcast_best<DUAL ? 1 : 0>(ncv);
   const int qn = nc.idx, sdn = nc.aux;
   const bool tilen = (qn != 0 && (qn >> 9) == (int)blockIdx.x); // 512 columns per tile
   if (tilen) {
@@ -1314,6 +1314,7 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
         if (i > m) break;
         const double a = c->T[(size_t)i * ld + qn];
         c->colqx[nxt][i] = a;
+        if (DUAL) continue; // the dual side needs the column only: its leaving row is chosen from column 0 by k_da
         double beta, lb = c->blb[i], ub = c->bub[i];
         if (step == ST_PIVOT) {
           if (i == p) {
@@ -1327,11 +1328,11 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
         } else {
           beta = c->T[(size_t)i * ld];
         }
-        Cand x;
+        Cand x{0.0, 0.0, 0, 0};
         if (ratio_row(a, sdn, beta, lb, ub, 0, c->tol_piv, i, x) && cand_better<1>(x, best)) best = x;
       }
       best = wave_best<1>(best);
-      if (TIDX == 0) c->rp[blockIdx.y] = best;
+      if (TIDX == 0 && !DUAL) c->rp[blockIdx.y] = best;
     }
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && TIDX == 0) {
@@ -1363,6 +1364,196 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
     }
     c->curA = nxt;
     c->nrb = (int)gridDim.y; // number of ratio-test partials this launch leaves for k_fa
+  }
+}
+
+// ======================================================================= fused dual path
+// The dual simplex (every warm start of a B&B child, bs.cpp:279,287) as the same two multi-workgroup kernels per pivot:
+//   k_da  (one block per 256 columns): the entering column q is the reduction of the dual-ratio partials left by the
+//         previous step; scales the pivot row into srow, updates the objective row, and -- before the bulk update runs
+//         -- chooses the NEXT leaving row from column 0 alone (beta' = fma(-colq, s0, beta), weights updated from the
+//         exported pivot column; every block does this O(m) pass redundantly: the keys are a total order), then
+//         prices that row as it will be after the update (fma(-colq[p'], s_j, T[p'][j])) and leaves new partials.
+//   k_fb<DUAL>: the streamed rank-1 update; the tile that owns the next entering column exports it contiguously.
+// Same arithmetic per entry as k_select / k_update in the dual phase (and the oracle's dual_simplex).
+__device__ __forceinline__ bool row_violation(double beta, double lb, double ub, double tol, double &viol, int &up) {
+  viol = 0.0;
+  up = 0;
+  if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) viol = lb - beta;
+  if (ub < INFINITY && beta > ub + tol * (1.0 + fabs(ub))) {
+    viol = beta - ub;
+    up = 1;
+  }
+  return viol > 0.0;
+}
+
+// one column's candidate in the dual ratio test of a row (dev_dual_ratio's body)
+__device__ __forceinline__ bool dual_ratio_col(double a, double d, int f, int to_upper, double tp, int j, Cand &x) {
+  if (f == MVX_NS) return false;
+  const double aa = to_upper ? -a : a;
+  double r;
+  if (aa > tp && (f == MVX_NL || f == MVX_NF)) r = (f == MVX_NF) ? fabs(d) : (d < 0.0 ? -d : 0.0);
+  else if (aa < -tp && (f == MVX_NU || f == MVX_NF)) r = (f == MVX_NF) ? fabs(d) : (d > 0.0 ? d : 0.0);
+  else return false;
+  const double mag = fabs(a);
+  x = Cand{xdiv(r, mag), mag, j, 0};
+  return true;
+}
+
+// bootstrap after a generic dual step: leaving row and dual-ratio partials from the tableau as it stands
+__global__ __launch_bounds__(256) void k_dboot(Ctl *c) {
+  __shared__ Cand lds[17];
+  const bool lead = (blockIdx.x == 0 && TIDX == 0);
+  if (c->done != D_RUN || c->phase != PH_DUAL || c->stall >= c->stall_limit || c->perturbed) {
+    if (lead) c->fstate = F_OFF;
+    return;
+  }
+  const int a = c->curA & 1, m = c->m, n = c->n;
+  const size_t ld = (size_t)c->ld;
+  const double *T = c->T, *w = c->dwx[a];
+  const double tol = c->tol_bnd;
+  Cand rb{0.0, 0.0, 0, 0};
+  for (int i = 1 + TIDX; i <= m; i += 256) {
+    double viol;
+    int up;
+    if (row_violation(T[(size_t)i * ld], c->blb[i], c->bub[i], tol, viol, up)) {
+      Cand x{xdiv(viol * viol, w[i]), 0.0, i, up};
+      if (cand_better<0>(x, rb)) rb = x;
+    }
+  }
+  rb = block_best<0>(rb, lds);
+  const int p2 = rb.idx, p2_up = rb.aux;
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  Cand best{0.0, 0.0, 0, 0};
+  if (p2 && j >= 1 && j <= n) {
+    Cand x{0.0, 0.0, 0, 0};
+    if (dual_ratio_col(T[(size_t)p2 * ld + j], c->sgn * T[j], c->nflag[j], p2_up, c->tol_piv, j, x)) best = x;
+  }
+  __syncthreads();
+  best = block_best<1>(best, lds);
+  if (TIDX == 0) c->pp[a][blockIdx.x] = best;
+  if (lead) {
+    c->p_nextx[a] = p2;
+    c->p_up_nextx[a] = p2_up;
+    c->fstate = F_RUN_DUAL;
+    c->step = ST_NONE;
+    c->curB = a ^ 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_da(Ctl *c) {
+  __shared__ Cand lds[17];
+  // level 1
+  const int done = c->done, fstate = c->fstate, cur = c->curA, budget = c->budget;
+  const int stall = c->stall, stall_limit = c->stall_limit;
+  const int npb = c->npb, m = c->m, n = c->n;
+  const size_t ld = (size_t)c->ld;
+  double *const T = c->T;
+  double *const srow = c->srow;
+  const int *const nflag = c->nflag;
+  const double *const colq = c->colqx[cur];
+  const double *const betac = c->betac[cur];
+  const Cand *const pp = c->pp[cur];
+  Cand *const ppn = c->pp[cur ^ 1];
+  const double *const dwc = c->dwx[cur & 1];
+  double *const dwn = c->dwx[(cur & 1) ^ 1];
+  const double sgn = c->sgn, tol_bnd = c->tol_bnd, tol_piv = c->tol_piv;
+  const int p = c->p_nextx[cur & 1], p_up = c->p_up_nextx[cur & 1];
+  if (done != D_RUN || fstate != F_RUN_DUAL) return;
+  const bool lead = (blockIdx.x == 0 && TIDX == 0);
+  const int lane = TIDX & 63;
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  const bool act = (j <= n);
+  // level 2: the entering column (smallest dual ratio), this lane's own entries
+  Cand pc = (lane < npb) ? pp[lane] : Cand{0.0, 0.0, 0, 0};
+  const double dold = act ? T[j] : 0.0;
+  const int fj = (act && j >= 1) ? nflag[j] : MVX_NS;
+  for (int k = lane + 64; k < npb; k += 64) {
+    Cand x = pp[k];
+    if (cand_better<1>(x, pc)) pc = x;
+  }
+  pc = wave_bcast_best<1>(pc);
+  // no leaving row (primal feasible: the phase ends), no entering column (dual unbounded), no budget, or a stalled run
+  // that Bland's rule must take over: the generic path continues
+  if (p == 0 || pc.idx == 0 || budget == 0 || stall >= stall_limit) {
+    if (lead) c->fstate = F_STOP;
+    return;
+  }
+  const int q = pc.idx;
+  // level 3
+  const double piv = colq[p], dq = colq[0], wp = dwc[p];
+  const double plb = c->blb[p], pub = c->bub[p];
+  const double lbq = c->nlb[q], ubq = c->nub[q];
+  const int fq = nflag[q];
+  const double v = act ? T[(size_t)p * ld + j] : 0.0;
+  const double bound = p_up ? pub : plb;
+  const int lf = dev_leave_flag(plb, pub, p_up);
+  const double xq = dev_nb_value(fq, lbq, ubq);
+  const double s0 = xdiv(betac[p] - bound, piv);
+  double sj = 0.0, dnew = 0.0;
+  if (act) {
+    sj = (j == 0) ? s0 : xdiv(v, piv);
+    srow[j] = sj;
+    dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dold);
+    T[j] = dnew;
+  }
+  // level 4: the next leaving row, from column 0 as the update will leave it, with the updated dual devex weights
+  Cand rb{0.0, 0.0, 0, 0};
+  for (int i = 1 + TIDX; i <= m; i += 256) {
+    const double ci = colq[i];
+    double beta, lb, ub, w;
+    if (i == p) {
+      beta = xq - s0;
+      lb = lbq;
+      ub = ubq;
+      const double cc = xdiv(wp, piv * piv);
+      w = cc > 1.0 ? cc : 1.0;
+    } else {
+      beta = fma(-ci, s0, betac[i]);
+      lb = c->blb[i];
+      ub = c->bub[i];
+      const double r = xdiv(ci, piv);
+      const double cc = r * r * wp;
+      w = dwc[i];
+      if (cc > w) w = cc;
+    }
+    if (blockIdx.x == 0) dwn[i] = w;
+    double viol;
+    int up;
+    if (row_violation(beta, lb, ub, tol_bnd, viol, up)) {
+      Cand x{xdiv(viol * viol, w), 0.0, i, up};
+      if (cand_better<0>(x, rb)) rb = x;
+    }
+  }
+  rb = block_best<0>(rb, lds);
+  const int p2 = rb.idx, p2_up = rb.aux;
+  // level 5: that row as the update will leave it, priced against the updated objective row
+  Cand best{0.0, 0.0, 0, 0};
+  if (p2 && act && j >= 1) {
+    double a2;
+    if (p2 == p) a2 = (j == q) ? xdiv(1.0, piv) : -sj;
+    else a2 = (j == q) ? xdiv(colq[p2], piv) : fma(-colq[p2], sj, T[(size_t)p2 * ld + j]);
+    Cand x{0.0, 0.0, 0, 0};
+    if (dual_ratio_col(a2, sgn * dnew, (j == q) ? lf : fj, p2_up, tol_piv, j, x)) best = x;
+  }
+  __syncthreads();
+  best = block_best<1>(best, lds);
+  if (TIDX == 0) ppn[blockIdx.x] = best;
+  if (lead) {
+    c->step = ST_PIVOT;
+    c->p = p;
+    c->q = q;
+    c->p_up = p_up;
+    c->piv = piv;
+    c->bound = bound;
+    c->xq = xq;
+    c->leave_flag = lf;
+    c->ent_lb = lbq;
+    c->ent_ub = ubq;
+    c->curB = cur;
+    c->stall_new = (pc.k1 <= DEGEN_TOL) ? stall + 1 : 0;
+    c->p_nextx[(cur & 1) ^ 1] = p2;
+    c->p_up_nextx[(cur & 1) ^ 1] = p2_up;
   }
 }
 
@@ -1506,7 +1697,7 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
       Cand best{0.0, 0.0, 0, 0};
       if (TIDX < 64) {
         if (TIDX < nc) {
-          Cand x;
+          Cand x{0.0, 0.0, 0, 0};
           if (price_col(my_nflag, sgn * tile[(size_t)TIDX * R], tol_dj, j0 + TIDX, my_w, x)) best = x;
         }
         best = wave_best<0>(best);
@@ -1521,8 +1712,10 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
         const double *col = tile + (size_t)cq * R;
         Cand rb{0.0, 0.0, 0, 0};
         for (int i = 1 + TIDX; i < R; i += 256) {
-          Cand x;
-          if (ratio_row(col[i], sdir, beta[i], blb[i], bub[i], 0, tol_piv, i, x) && cand_better<1>(x, rb)) rb = x;
+          Cand x{0.0, 0.0, 0, 0};
+          if (ratio_row(col[i], sdir, beta[i], blb[i], bub[i], 0, tol_piv, i, x)) {
+            if (cand_better<1>(x, rb)) rb = x;
+          }
         }
         const Cand r = block_best<1>(rb, lds);
         // the column's own bounds / status live in lane cq of wave 0
@@ -1992,12 +2185,25 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
   const int nt = pick_nt(m, n);
   dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
 #define FB_CASE(TR_, HOT_, NT_) \
-  if (tr == TR_ && g_hot == HOT_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
+  if (tr == TR_ && g_hot == HOT_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_, 0>), grid, dim3(256), 0, s, d_ctl); return; }
   FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
   FB_CASE(8, 0, 0) FB_CASE(32, 0, 0) FB_CASE(8, 0, 1) FB_CASE(16, 0, 1) FB_CASE(32, 0, 1)
   FB_CASE(4, 1, 0) FB_CASE(4, 0, 0) FB_CASE(4, 1, 1) FB_CASE(4, 0, 1)
 #undef FB_CASE
   std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
+}
+void launch_dboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_dboot, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
+void launch_da(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_da, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
+void launch_db(Ctl *d_ctl, int m, int n, hipStream_t s) {
+  const int pairs = (n + 2) / 2;
+  const int tr = pick_tr(m, n);
+  const int nt = pick_nt(m, n);
+  dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
+#define DB_CASE(TR_, NT_) \
+  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, 1, NT_, 1>), grid, dim3(256), 0, s, d_ctl); return; }
+  DB_CASE(16, 0) DB_CASE(16, 1) DB_CASE(8, 0) DB_CASE(8, 1) DB_CASE(4, 0) DB_CASE(4, 1) DB_CASE(32, 0) DB_CASE(32, 1)
+#undef DB_CASE
+  std::abort(); // unreachable
 }
 void launch_select(Ctl *d_ctl, hipStream_t s, int slots) {
   BatchQueue q{};

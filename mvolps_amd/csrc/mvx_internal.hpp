@@ -35,7 +35,7 @@ enum : int { D_RUN = 0, D_OPT = 1, D_UNBND = 2, D_NOFEAS = 3, D_ITLIM = 4, D_PFE
 // step kinds
 enum : int { ST_NONE = 0, ST_PIVOT = 1, ST_FLIP = 2, ST_STOP = 3 };
 // fused primal fast path state
-enum : int { F_OFF = 0, F_RUN = 1, F_STOP = 2 };
+enum : int { F_OFF = 0, F_RUN = 1, F_STOP = 2, F_RUN_DUAL = 3 };
 
 // reduction candidate: (k1, k2, idx) is a strict total order, aux rides along
 struct Cand {
@@ -96,6 +96,11 @@ struct Ctl {
   int n_edits, edit_row[MAX_EDITS];
   double edit_lb[MAX_EDITS], edit_ub[MAX_EDITS];
   int job; // batched solve: which job of the queue this slot is working on (-1: none)
+  // fused dual path (k_dboot / k_da / k_fb<DUAL>): dual devex weights in two sets (the current one is dwx[curA & 1];
+  // the generic path updates it in place, k_da writes the other and k_fb flips curA), and the leaving row of the
+  // NEXT pivot, chosen by k_da from column 0 before the bulk update (ping-pong like the other fused buffers)
+  double *dwx[2];
+  int p_nextx[2], p_up_nextx[2];
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots

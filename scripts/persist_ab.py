@@ -37,7 +37,7 @@ for (m, n) in [tuple(int(v) for v in s.split("x")) for s in os.environ.get("AB_S
     api.persist_stats(C.byref(la), C.byref(ab))
     row["same_bits"] = len(set(objs)) == 1 and row["persist_full"] == row["two_kernel_full"]
     row["launches"], row["aborts"] = la.value, ab.value
-    cyc = (C.c_ulonglong * 8)()
+    cyc = (C.c_ulonglong * 64)()
     api.persist_cycles(cyc)
     tot = list(cyc)
     row["cycles_per_pivot_cumulative"] = {k: tot[i] / max(1, tot[4]) for i, k in enumerate(("propose", "gather", "read", "apply"))}

@@ -528,3 +528,21 @@ def test_glpk_default_tolerances_behind_null_parameters(gpu, orc):
     finally:
         for a in (gpu, orc):
             a.set_default_tolerances(1e-9, 1e-9, 1e-9)
+
+
+@pytest.mark.parametrize("case", [(358, 124, 41004, 0.8), (288, 252, 41002, 0.8), (314, 433, 41000, 0.95), (390, 253, 41024, 0.8)],
+                         ids=lambda c: "%dx%d" % (c[0], c[1]))
+def test_degenerate_lps_through_the_resident_tableau_kernel(gpu, orc, case):
+    """Massively degenerate, boxed LPs at sizes the resident-tableau kernel takes (k_persist): ties in every ratio
+    test, bound flips, steps of length zero.  (scripts/fuzz_large.py found the first version of that kernel choosing
+    the right leaving row with the wrong bound on exactly these -- a candidate struct left uninitialised on one
+    path; every reduction candidate is value-initialised now.)"""
+    m, n, seed, frac0 = case
+    A, b, c = lpgen.degenerate_lp(m, n, seed, frac0=frac0)
+    g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+    for P in (g, o):
+        P.simplex()
+    assert g.status == o.status and g.it_cnt == o.it_cnt
+    assert np.array_equal(g.tableau(), o.tableau())
+    for u, v in zip(g.basis(), o.basis()):
+        assert np.array_equal(u, v)
