@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   const double *colq = c->colqx[cur];
   double *bnew = c->betac[nxt];
   // pricing partial of the NEXT step: requested now, reduced after the stream has been issued
-  const int npb = c->npb;
+  const int npb = DUAL ? c->npbd : c->npb;
   const Cand *ppn = c->pp[nxt];
   Cand ncv = ((TIDX & 63) < npb) ? ppn[TIDX & 63] : Cand{0.0, 0.0, 0, 0};
   if (step == ST_PIVOT) {
@@ -1401,7 +1401,7 @@ __device__ __forceinline__ bool dual_ratio_col(double a, double d, int f, int to
 }
 
 // bootstrap after a generic dual step: leaving row and dual-ratio partials from the tableau as it stands
-__global__ __launch_bounds__(256) void k_dboot(Ctl *c) {
+__global__ __launch_bounds__(DA_THREADS) void k_dboot(Ctl *c) {
   __shared__ Cand lds[17];
   const bool lead = (blockIdx.x == 0 && TIDX == 0);
   if (c->done != D_RUN || c->phase != PH_DUAL || c->stall >= c->stall_limit || c->perturbed) {
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_dboot(Ctl *c) {
   const double *T = c->T, *w = c->dwx[a];
   const double tol = c->tol_bnd;
   Cand rb{0.0, 0.0, 0, 0};
-  for (int i = 1 + TIDX; i <= m; i += 256) {
+  for (int i = 1 + TIDX; i <= m; i += DA_THREADS) {
     double viol;
     int up;
     if (row_violation(T[(size_t)i * ld], c->blb[i], c->bub[i], tol, viol, up)) {
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_dboot(Ctl *c) {
   }
   rb = block_best<0>(rb, lds);
   const int p2 = rb.idx, p2_up = rb.aux;
-  const int j = (int)blockIdx.x * 256 + TIDX;
+  const int j = (int)blockIdx.x * DA_THREADS + TIDX;
   Cand best{0.0, 0.0, 0, 0};
   if (p2 && j >= 1 && j <= n) {
     Cand x{0.0, 0.0, 0, 0};
@@ -1438,15 +1438,16 @@ __global__ __launch_bounds__(256) void k_dboot(Ctl *c) {
     c->fstate = F_RUN_DUAL;
     c->step = ST_NONE;
     c->curB = a ^ 1;
+    c->npbd = (int)gridDim.x;
   }
 }
 
-__global__ __launch_bounds__(256) void k_da(Ctl *c) {
+__global__ __launch_bounds__(DA_THREADS) void k_da(Ctl *c) {
   __shared__ Cand lds[17];
   // level 1
   const int done = c->done, fstate = c->fstate, cur = c->curA, budget = c->budget;
   const int stall = c->stall, stall_limit = c->stall_limit;
-  const int npb = c->npb, m = c->m, n = c->n;
+  const int npb = c->npbd, m = c->m, n = c->n;
   const size_t ld = (size_t)c->ld;
   double *const T = c->T;
   double *const srow = c->srow;
@@ -1462,7 +1463,7 @@ __global__ __launch_bounds__(256) void k_da(Ctl *c) {
   if (done != D_RUN || fstate != F_RUN_DUAL) return;
   const bool lead = (blockIdx.x == 0 && TIDX == 0);
   const int lane = TIDX & 63;
-  const int j = (int)blockIdx.x * 256 + TIDX;
+  const int j = (int)blockIdx.x * DA_THREADS + TIDX;
   const bool act = (j <= n);
   // level 2: the entering column (smallest dual ratio), this lane's own entries
   Cand pc = (lane < npb) ? pp[lane] : Cand{0.0, 0.0, 0, 0};
@@ -1499,7 +1500,7 @@ __global__ __launch_bounds__(256) void k_da(Ctl *c) {
   }
   // level 4: the next leaving row, from column 0 as the update will leave it, with the updated dual devex weights
   Cand rb{0.0, 0.0, 0, 0};
-  for (int i = 1 + TIDX; i <= m; i += 256) {
+  for (int i = 1 + TIDX; i <= m; i += DA_THREADS) {
     const double ci = colq[i];
     double beta, lb, ub, w;
     if (i == p) {
@@ -2192,8 +2193,8 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
 #undef FB_CASE
   std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
 }
-void launch_dboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_dboot, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
-void launch_da(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_da, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
+void launch_dboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_dboot, dim3((n + DA_THREADS) / DA_THREADS), dim3(DA_THREADS), 0, s, d_ctl); }
+void launch_da(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_da, dim3((n + DA_THREADS) / DA_THREADS), dim3(DA_THREADS), 0, s, d_ctl); }
 void launch_db(Ctl *d_ctl, int m, int n, hipStream_t s) {
   const int pairs = (n + 2) / 2;
   const int tr = pick_tr(m, n);

@@ -25,6 +25,7 @@ constexpr int ROW_SLACK = 64;     // spare tableau rows per handle for cut appen
 constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this counts as degenerate (oracle: DEGEN_TOL)
 constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
+constexpr int DA_THREADS = 1024; // k_dboot / k_da workgroup size: the O(m) leaving-row pass is redundant per block
 constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
 
@@ -101,6 +102,7 @@ struct Ctl {
   // NEXT pivot, chosen by k_da from column 0 before the bulk update (ping-pong like the other fused buffers)
   double *dwx[2];
   int p_nextx[2], p_up_nextx[2];
+  int npbd; // number of dual-ratio partials (k_da blocks of DA_THREADS columns)
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots
