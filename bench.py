@@ -432,11 +432,32 @@ def main():
             }
 
     dist_leg = None
-    if dist is not None and world > 1:
-        try:
-            dist_leg = dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, args.bnb_nodes)
-        except Exception as e:  # every rank raises or none does (the failure modes are deterministic: fixture, engine)
-            dist_leg = {"error": repr(e)}
+    leg_hung = False
+    if dist is not None and world > 1 and os.environ.get("MVX_BENCH_NO_DIST_BNB") != "1":
+        # The B&B farm is a side measurement: it must never cost the headline line.  It runs on a helper thread with a
+        # deadline; if a rank stalls in a collective (a transport problem on a node this code has not met), every rank
+        # gives up at its own deadline, rank 0 prints the line with the leg marked as timed out, and the process leaves
+        # without waiting for the stuck collective.
+        import threading
+
+        box = {}
+
+        def leg():
+            try:
+                torch.cuda.set_device(dev_index)
+                api.bind_thread()
+                box["res"] = dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, args.bnb_nodes)
+            except Exception as e:  # the failure modes that raise are deterministic (fixture, engine): every rank raises
+                box["res"] = {"error": repr(e)}
+
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("MVX_BENCH_DIST_DEADLINE", "240")))
+        if th.is_alive():
+            leg_hung = True
+            dist_leg = {"error": "timed out after %s s (a rank stalled in a collective); headline unaffected" % os.environ.get("MVX_BENCH_DIST_DEADLINE", "240")}
+        else:
+            dist_leg = box.get("res")
 
     out = None
     if rank == 0:
@@ -477,9 +498,25 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(m, n, args.seed)
         print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    if leg_hung:
+        os._exit(0)  # a collective is stuck on the helper thread: leave without joining it
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        # leave together, but never wait for a peer that gave up on the side leg
+        import threading
+
+        def bye():
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:
+                pass
+
+        th = threading.Thread(target=bye, daemon=True)
+        th.start()
+        th.join(60.0)
+        if th.is_alive():
+            os._exit(0)
 
 
 if __name__ == "__main__":

@@ -213,6 +213,9 @@ void mvx_sync(void);
    split mvx_branchAndBound makes -- batch solves on a worker thread while the calling thread clones, edits, queries
    and deletes OTHER handles. */
 int mvx_last_error(void);
+/* HIP's current device is per host thread: a thread other than the one that made the first engine call calls this
+   once before it uses handles (0 on success) */
+int mvx_bind_thread(void);
 
 #ifdef __cplusplus
 }

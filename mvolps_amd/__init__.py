@@ -29,6 +29,7 @@ _EXTRA = {
     "row_residual": (C.c_double, [C.c_void_p]),
     "persist_stats": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "last_error": (C.c_int, []),
+    "bind_thread": (C.c_int, []),
     "persist_cycles": (None, [C.POINTER(C.c_ulonglong)]),
     "simplex_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "pack_size": (C.c_longlong, [C.c_void_p]),

@@ -462,5 +462,6 @@ long long mvx_profile_update_launches(void) { return mvx::profile_update_launche
 double mvx_last_solve_ms(const mvx_prob *P) { return P->last_ms; }
 void mvx_sync(void) { mvx::sync_stream(); }
 int mvx_last_error(void) { return mvx::take_last_error(); }
+int mvx_bind_thread(void) { return mvx::bind_thread(); }
 
 } // extern "C"

@@ -188,6 +188,12 @@ static void init_solve_ctx(SolveCtx &sc) {
 
 int take_last_error() { return g_last_error.exchange(0); }
 
+// the current device is per host thread: a thread other than the one that made the first engine call binds itself
+int bind_thread() {
+  if (!g_ctx) return -1;
+  return hipSetDevice(g_ctx->dev) == hipSuccess ? 0 : -1;
+}
+
 static Context &ctx() {
   std::lock_guard<std::mutex> lk(g_ctx_mu);
   if (g_ctx) return *g_ctx;

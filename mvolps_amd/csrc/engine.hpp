@@ -8,6 +8,7 @@ int device_count();
 int set_device(int dev);
 void sync_stream();
 int take_last_error(); // MVX_ENOMEM ... since the last call; clears it
+int bind_thread();
 
 // solve (glp_simplex)
 int engine_simplex(mvx_prob *P, const mvx_smcp *parm);
