@@ -703,7 +703,7 @@ static void flush_update_events(Context &c, size_t used) {
 // A solve is a small host-side state machine around queued launches, so that several of them
 // can be in flight on different streams (engine_simplex_batch): begin -> {enqueue, sync, collect}*.
 // ---- resident-tableau path (k_persist): which problems take it, its buffers, backup and restore
-constexpr int PERSIST_HEAD_STRIDE_MAX = 1024; // granules (8 KB) between two strips' heads at most
+constexpr int PERSIST_HEAD_STRIDE_MAX = 4; // granules between two strips' heads
 static int g_persist_mode = -1;      // -1: environment MVX_PERSIST (default on), 0 off, 1 on
 static bool g_persist_broken = false; // a launch aborted (its workgroups were not co-resident in time): off for good
 static long long g_persist_launches = 0, g_persist_aborts = 0;
@@ -896,14 +896,8 @@ static void job_enqueue(Context &c, SolveJob &J) {
         HIPCHECK(hipMemcpyAsync(sc.d_pctl, sc.d_ctl, sizeof(Ctl), hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw, sc.d_pw[0], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw + P->ld, sc.d_pw[1], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
-        static int head_stride = 0;
-        if (!head_stride) {
-          const char *e = std::getenv("MVX_PERSIST_HS");
-          head_stride = e ? std::atoi(e) : 4;
-          if (head_stride < 4 || head_stride > PERSIST_HEAD_STRIDE_MAX) head_stride = 4;
-        }
+        const int head_stride = 4; // 4 B .. 4 KB between heads measured the same
         HIPCHECK(hipMemsetAsync(sc.d_pcand, 0, (size_t)2 * pl.nw * head_stride * 8, sc.stream));
-        if (std::getenv("MVX_PERSIST_ZERO_SLOTS")) HIPCHECK(hipMemsetAsync(sc.d_pmsg, 0, (size_t)2 * 256 * sc.p_msg_words * 8, sc.stream));
         const int steps = 1 << 24; // the pivot limit is the control block's `budget`, which the kernel counts down
         if (launch_persist(sc.d_ctl, sc.d_pcand, sc.d_pmsg, sc.d_pabort, (unsigned long long *)(sc.d_pabort + 16), P->m, pl.cpw, pl.nw, sc.p_msg_words, steps, head_stride, sc.stream) == 0) {
           J.persist_queued = true;

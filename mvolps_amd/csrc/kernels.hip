@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "mvx_internal.hpp"
 
@@ -1918,6 +1919,13 @@ __global__ __launch_bounds__(256) void k_persist(PersistArgs a) {
     it++;
     __syncthreads();
     t_appl += clock64() - c3;
+  }
+  if (TIDX == 0 && a.dbg && steps > 0) { // spread of the per-workgroup work (propose + read + apply) and gather, cycles per pivot
+    const unsigned long long work = (unsigned long long)((t_prop + t_read + t_appl) / steps), gat = (unsigned long long)(t_gath / steps);
+    atomicMax(&a.dbg[8], work);
+    atomicMax(&a.dbg[9], ~work); // min via max of the complement
+    atomicMax(&a.dbg[10], gat);
+    atomicMax(&a.dbg[11], ~gat);
   }
   if (w == 0 && TIDX == 0 && a.dbg) {
     a.dbg[0] += (unsigned long long)t_prop; a.dbg[1] += (unsigned long long)t_gath; a.dbg[2] += (unsigned long long)t_read;

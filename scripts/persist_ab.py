@@ -43,5 +43,7 @@ for (m, n) in [tuple(int(v) for v in s.split("x")) for s in os.environ.get("AB_S
     row["cycles_per_pivot_cumulative"] = {k: tot[i] / max(1, tot[4]) for i, k in enumerate(("propose", "gather", "read", "apply"))}
     row["cycles_per_pivot_cumulative"]["sweeps"] = tot[5] / max(1, tot[4])
     row["cycles_per_pivot_cumulative"]["first_sweep"] = tot[6] / max(1, tot[4])
+    M = (1 << 64) - 1
+    row["spread_last_launches"] = {"work_max": tot[8], "work_min": M - tot[9], "gather_max": tot[10], "gather_min": M - tot[11]}
     row["frac_hbm_roofline_persist"] = 16 * (m + 1) * (n + 1) / (row["persist_us_per_pivot"] * 1e-6) / 8e12
     print(json.dumps(row), flush=True)
