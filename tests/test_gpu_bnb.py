@@ -130,20 +130,45 @@ def test_config3_efficacy_selected_cuts_at_size(gpu, orc):
     same_result(got, ref)
 
 
-def test_cli_end_to_end_f1(gpu, tmp_path):
-    """Config 1 plumbing: `mvolps -f f1.lp` (2test.cpp main) -> reader -> B&B on the GPU -> tree + solution."""
+def test_cli_end_to_end_f1(gpu, orc, tmp_path):
+    """Config 1 plumbing: `mvolps -f f1.lp` (2test.cpp main) -> reader -> B&B on the GPU -> event stream, tree report and
+    solution line.  The three texts are compared WHOLE with what the same driver writes from a run over the oracle's
+    engine (message.h:141-226 line format, bs.cpp:329-345 report): every event line, every tree line, the solution."""
+    import ctypes as C
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "mvolps_amd", "bin", "mvolps")
+    # the oracle-side rendering of the same run
+    f1 = GOLD["ilp"][0]
+    A, b, c = np.array(f1["A"]), np.array(f1["b"]), np.array(f1["c"])
+    L = bnb.lib()
+    L.mvx_bnb_write_events.argtypes = [C.POINTER(bnb.BnbResult), C.c_char_p]
+    L.mvx_bnb_print_tree.argtypes = [C.POINTER(bnb.BnbResult), C.c_char_p]
+    L.mvx_bnb_solution_string.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(bnb.BnbResult), C.c_char_p, C.c_int]
+    P = lpgen.load_ilp(orc, A, b, c, np.inf)
+    tab = bnb.table_from(orc)
+    pr = bnb.make_params(quirks=0)
+    res = bnb.BnbResult()
+    L.mvx_branchAndBound(C.cast(C.pointer(tab), C.c_void_p), P.h, C.byref(pr), C.byref(res))
+    ev_ref, tree_ref = str(tmp_path / "ev_ref.txt"), str(tmp_path / "tree_ref.txt")
+    assert L.mvx_bnb_write_events(C.byref(res), ev_ref.encode()) == 0 and L.mvx_bnb_print_tree(C.byref(res), tree_ref.encode()) == 0
+    buf = C.create_string_buffer(4096)
+    assert L.mvx_bnb_solution_string(C.cast(C.pointer(tab), C.c_void_p), P.h, C.byref(res), buf, 4096) == 0
+    sol_ref = buf.value.decode().strip()
+    L.mvx_bnb_free_result(C.byref(res))
+    assert sol_ref.endswith("= 35") and len(open(ev_ref).read().splitlines()) > 10
     for ext in ("lp", "mps"):
         ev = tmp_path / ("ev_%s.txt" % ext)
         r = subprocess.run([exe, "-f", os.path.join(root, "tests", "golden", "f1." + ext), "--repaired", "-v", "--events", str(ev)],
                            capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
-        assert "[I = Integral node, F = Infeasible node, B = Worse bound node]" in r.stdout
-        assert "Solution is: 3*(x[3] = 7) + 7*(x[4] = 2) + 0 = 35" in r.stdout
-        assert open(ev).read().splitlines()[-1] == "END"
+        assert open(ev).read() == open(ev_ref).read()  # the whole event stream, line for line
+        out = r.stdout.splitlines()
+        t0 = out.index("[I = Integral node, F = Infeasible node, B = Worse bound node]")
+        tree = open(tree_ref).read().splitlines()
+        assert out[t0:t0 + len(tree)] == tree  # the whole tree report
+        assert sol_ref in r.stdout and "Solution is: 3*(x[3] = 7) + 7*(x[4] = 2) + 0 = 35" in r.stdout
     r = subprocess.run([exe, "-f", "nope.txt"], capture_output=True, text=True)
     assert "Unrecognized filetype" in r.stdout
 
