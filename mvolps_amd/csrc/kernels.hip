@@ -831,7 +831,7 @@ void launch_refresh_select(Ctl *d_ctl, const int *tflag, int var, hipStream_t s)
 // ---------------------------------------------------------------------------- k_update
 template <int NT>
 __device__ __forceinline__ double2 ld2(const double2 *p) {
-  if (NT) {
+  if (NT == 1) {
     double2 v;
     v.x = __builtin_nontemporal_load(&p->x);
     v.y = __builtin_nontemporal_load(&p->y);
@@ -841,7 +841,14 @@ __device__ __forceinline__ double2 ld2(const double2 *p) {
 }
 template <int NT>
 __device__ __forceinline__ void st2(double2 *p, double2 v) {
-  if (NT) {
+  if (NT == 2) {
+    // write-through store (sc1): the line goes to memory as it is written instead of waiting in L2 as a dirty line for
+    // its eviction.  Measured on tableaux around the Infinity Cache size (scripts/ntsweep.py); the s_nop covers the
+    // wait state a >8-byte store needs before its data registers may be rewritten (inline asm is not hazard-checked).
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v w = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+  } else if (NT == 1) {
     __builtin_nontemporal_store(v.x, &p->x);
     __builtin_nontemporal_store(v.y, &p->y);
   } else
@@ -2165,16 +2172,19 @@ static int g_tr = 0, g_hot = 1, g_nt = -1; // g_tr 0 = pick from the grid size; 
 void set_tuning(int tr, int hot, int nt) {
   g_tr = (tr == 4 || tr == 8 || tr == 16 || tr == 32) ? tr : 0;
   g_hot = hot ? 1 : 0;
-  g_nt = (nt == 0 || nt == 1) ? nt : -1;
+  g_nt = (nt >= 0 && nt <= 2) ? nt : -1; // 0 plain, 1 non-temporal, 2 write-through stores; anything else: by size
 }
-// Non-temporal loads and stores once the tableau no longer fits the 256 MiB Infinity Cache: every entry is touched
-// once per pivot, so lines kept for reuse only evict each other -- 8192x8192 (537 MB): 5.34 -> 6.13 TB/s
-// (profiles/r02_sweep_nt_8192x8192.jsonl).  Below that size the cache holds most of the tableau from one pivot to
-// the next and the default policy is faster (round 1's sweep at 4096x8192).
+// How the update kernels touch the tableau, by its size (scripts/ntsweep.py, profiles/r02_ntsweep_sizes.jsonl):
+//   1  non-temporal loads and stores once the tableau no longer fits the 256 MiB Infinity Cache: every entry is touched
+//      once per pivot, so lines kept for reuse only evict each other -- 8192x8192 (537 MB): 5.34 -> 6.13 TB/s;
+//   2  write-through stores (sc1) from about 100 MiB up to the cache size: the cache still serves the loads, and a line
+//      written through does not sit in L2 as a dirty line until evicted -- 3-4 % less time per launch at 145-257 MiB;
+//   0  plain access below that (a tie at 65 MiB) and in the narrow band between the two (289 MiB: plain is fastest).
 static int pick_nt(int m, int n) {
   if (g_nt >= 0) return g_nt;
   const size_t bytes = (size_t)(m + 1) * (size_t)((n + 1 + LD_ALIGN - 1) / LD_ALIGN * LD_ALIGN) * 8;
-  return bytes > NT_THRESHOLD_BYTES ? 1 : 0;
+  if (bytes > NT_THRESHOLD_BYTES) return 1;
+  return (bytes >= WT_MIN_BYTES && bytes <= WT_MAX_BYTES) ? 2 : 0;
 }
 // row-block depth: 16 rows per block once that still gives every CU several blocks, else 8
 static int pick_tr(int m, int n) {
@@ -2195,7 +2205,7 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
   dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
 #define FB_CASE(TR_, HOT_, NT_) \
   if (tr == TR_ && g_hot == HOT_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_, 0>), grid, dim3(256), 0, s, d_ctl); return; }
-  FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
+  FB_CASE(16, 1, 2) FB_CASE(8, 1, 2) FB_CASE(4, 1, 2) FB_CASE(32, 1, 2) FB_CASE(16, 0, 2) FB_CASE(8, 0, 2) FB_CASE(4, 0, 2) FB_CASE(32, 0, 2) FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
   FB_CASE(8, 0, 0) FB_CASE(32, 0, 0) FB_CASE(8, 0, 1) FB_CASE(16, 0, 1) FB_CASE(32, 0, 1)
   FB_CASE(4, 1, 0) FB_CASE(4, 0, 0) FB_CASE(4, 1, 1) FB_CASE(4, 0, 1)
 #undef FB_CASE
@@ -2211,6 +2221,7 @@ void launch_db(Ctl *d_ctl, int m, int n, hipStream_t s) {
 #define DB_CASE(TR_, NT_) \
   if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, 1, NT_, 1>), grid, dim3(256), 0, s, d_ctl); return; }
   DB_CASE(16, 0) DB_CASE(16, 1) DB_CASE(8, 0) DB_CASE(8, 1) DB_CASE(4, 0) DB_CASE(4, 1) DB_CASE(32, 0) DB_CASE(32, 1)
+  DB_CASE(16, 2) DB_CASE(8, 2) DB_CASE(4, 2) DB_CASE(32, 2)
 #undef DB_CASE
   std::abort(); // unreachable
 }
@@ -2227,7 +2238,9 @@ void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
   // 16-row tiles once the launch still has >= 2048 workgroups, else 8, else 4 (latency-bound sizes)
   const int tr = ((long)((m + 16) / 16) * tiles * slots >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * slots >= 2048) ? 8 : 4;
   dim3 grid((unsigned)tiles, (m + tr) / tr, slots);
-  if (tr == 16 && pick_nt(m, n)) hipLaunchKernelGGL((k_update<16, 1>), grid, dim3(256), 0, s, d_ctl);
+  const int nt = (tr == 16) ? pick_nt(m, n) : 0;
+  if (nt == 1) hipLaunchKernelGGL((k_update<16, 1>), grid, dim3(256), 0, s, d_ctl);
+  else if (nt == 2) hipLaunchKernelGGL((k_update<16, 2>), grid, dim3(256), 0, s, d_ctl);
   else if (tr == 16) hipLaunchKernelGGL((k_update<16, 0>), grid, dim3(256), 0, s, d_ctl);
   else if (tr == 8) hipLaunchKernelGGL((k_update<8, 0>), grid, dim3(256), 0, s, d_ctl);
   else hipLaunchKernelGGL((k_update<4, 0>), grid, dim3(256), 0, s, d_ctl);
