@@ -48,8 +48,8 @@ void set_tuning(int tr, int hot, int nt);
 int fused_npb(int n);
 int fused_nrb_max(int m);
 void launch_fboot(Ctl *, int n, hipStream_t);
-void launch_fa(Ctl *, int n, hipStream_t);
-void launch_fb(Ctl *, int m, int n, hipStream_t);
+void launch_fa(Ctl *, int n, hipStream_t, int probe = 0);
+void launch_fb(Ctl *, int m, int n, hipStream_t, int boot = 0);
 void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
@@ -863,9 +863,9 @@ static void job_enqueue(Context &c, SolveJob &J) {
     return;
   }
   const int batch = J.batch;
-  if (J.profiled && c.ev_pool.size() < (size_t)2 * batch + 2) { // sized for the largest batch
+  if (J.profiled && c.ev_pool.size() < (size_t)2 * batch + 4) { // sized for the largest batch
     size_t old = c.ev_pool.size();
-    c.ev_pool.resize((size_t)2 * batch + 2);
+    c.ev_pool.resize((size_t)2 * batch + 4);
     for (size_t k = old; k < c.ev_pool.size(); k++) HIPCHECK(hipEventCreate(&c.ev_pool[k]));
   }
   // with a pivot limit, never queue more pivots than the limit still allows (+1 launch so that
@@ -877,21 +877,18 @@ static void job_enqueue(Context &c, SolveJob &J) {
   // (replaying each batch as one captured hipGraph was measured: no gain -- the dispatch of small kernels is
   // bound by the command processor, not by the host -- and removed)
   int depth;
-  if (J.try_fused) depth = std::max(0, std::min(batch - 1, remaining - 1));
+  if (J.try_fused) depth = std::max(0, std::min(batch, remaining)); // + the generic step that closes the batch, if the limit leaves it a pivot
   else depth = std::max(1, std::min(batch, remaining));
   auto body = [&](int m_grid) {
     if (J.try_fused) {
-      // one generic step settles the phase; if it is primal phase 2 the fused two-kernel pipeline
-      // (k_fa / k_fb) takes over, otherwise its launches return at once
-      launch_select(sc.d_ctl, sc.stream);
-      ev();
-      launch_update(sc.d_ctl, m_grid, n, sc.stream);
-      ev();
       PersistPlan pl;
       if (depth > 0 && !J.profiled && persist_plan(c, P, &pl) && ensure_persist(c, sc, P, pl)) {
-        // cache-resident size: the whole run of primal pivots in ONE launch with the tableau held in LDS.  In front
-        // of it a backup (slab, control block, both devex weight sets): a launch whose workgroups do not all become
-        // resident in time aborts mid-step, and the backup is what the two-kernel path then carries on from.
+        // cache-resident size: one generic step settles the phase, then the whole run of primal pivots in ONE launch
+        // with the tableau held in LDS.  In front of it a backup (slab, control block, both devex weight sets): a
+        // launch whose workgroups do not all become resident in time aborts mid-step, and the backup is what the
+        // two-kernel path then carries on from.
+        launch_select(sc.d_ctl, sc.stream);
+        launch_update(sc.d_ctl, m_grid, n, sc.stream);
         HIPCHECK(hipMemcpyAsync(sc.p_backup, P->slab, P->slab_bytes, hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_pctl, sc.d_ctl, sizeof(Ctl), hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw, sc.d_pw[0], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
@@ -908,15 +905,30 @@ static void job_enqueue(Context &c, SolveJob &J) {
         } else {
           g_persist_broken = true;
         }
-      } else if (depth > 0) {
-        launch_fboot(sc.d_ctl, n, sc.stream);
-        launch_fb(sc.d_ctl, m_grid, n, sc.stream);
-        for (int k = 0; k < depth; k++) {
-          launch_fa(sc.d_ctl, n, sc.stream);
-          ev();
-          launch_fb(sc.d_ctl, m_grid, n, sc.stream);
-          ev();
+      } else {
+        // The fused two-kernel pipeline (k_fa / k_fb) first: k_fboot takes a call from its very first pivot when the
+        // basis it starts from is primal feasible, and otherwise (dual simplex, phase 1, Bland's rule in force) turns
+        // the pipeline off, so that its launches return at once.  One generic step closes the batch: it settles what
+        // a stopped run ended on (optimum, unbounded ray, stall) in the same host round trip, and is an ordinary
+        // pivot when nothing stopped.  Its events come first in the pool: the leading pairs are the ones that stepped.
+        const size_t e_generic = J.ev_used;
+        if (J.profiled) J.ev_used += 2;
+        if (depth > 0) {
+          launch_fboot(sc.d_ctl, n, sc.stream);
+          launch_fb(sc.d_ctl, m_grid, n, sc.stream, 1);
+          for (int k = 0; k < depth; k++) {
+            launch_fa(sc.d_ctl, n, sc.stream);
+            ev();
+            launch_fb(sc.d_ctl, m_grid, n, sc.stream);
+            ev();
+          }
+          // a run that may end on the pivot limit: one more selection that only looks (k_fa reports the limit itself)
+          if (J.parm.it_lim >= 0 && depth >= remaining) launch_fa(sc.d_ctl, n, sc.stream, 1);
         }
+        launch_select(sc.d_ctl, sc.stream);
+        if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic], sc.stream));
+        launch_update(sc.d_ctl, m_grid, n, sc.stream);
+        if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic + 1], sc.stream));
       }
     } else if (J.try_dfused) {
       // one generic step settles the phase (and restarts the dual devex weights when the phase has just been

@@ -1028,21 +1028,49 @@ __device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, d
   return true;
 }
 
-// bootstrap: price the current objective row into pp[curA]; arm the fused path
+// bootstrap: price the current objective row into pp[curA]; arm the fused path.
+// A call that has just begun (phase PH_START, no bound edits waiting) is taken from its first pivot: every block repeats
+// select_step's opening check -- no basic variable outside its bounds by more than the tolerance -- and, if that holds,
+// the primal devex weights restart from one exactly as the generic step's `fresh_primal` does.  The phase itself is
+// written by the bootstrap k_fb (its lead lane), after every block of this kernel has read it.
 __global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
   __shared__ Cand lds[17];
-  if (c->done != D_RUN || c->phase != PH_PRIMAL2 || c->stall >= c->stall_limit) { // fused path has no Bland pricing
+  const int phase = c->phase;
+  const bool fresh = (phase == PH_START);
+  if (c->done != D_RUN || c->stall >= c->stall_limit || !(phase == PH_PRIMAL2 || (fresh && c->n_edits == 0))) { // no Bland pricing here
     if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
     return;
+  }
+  if (fresh) {
+    const int m = c->m;
+    const size_t ld = (size_t)c->ld;
+    const double tol = c->tol_bnd;
+    const double *T = c->T, *blb = c->blb, *bub = c->bub;
+    int bad = 0;
+    for (int i = 1 + TIDX; i <= m; i += 256) {
+      const double beta = T[(size_t)i * ld];
+      const double lb = blb[i], ub = bub[i];
+      if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) bad = 1;
+      if (ub < INFINITY && beta > ub + tol * (1.0 + fabs(ub))) bad = 1;
+    }
+    if (__syncthreads_or(bad)) { // not primal feasible: the generic step decides between the dual simplex and phase 1
+      if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
+      return;
+    }
   }
   // The ping-pong parity stays where the last fused run left it (curA): the current devex weights live in
   // pw[curA].  The bootstrap k_fb reads side curB = curA^1 and flips curA back to where it is now.
   const int a = c->curA & 1;
   const int j = (int)blockIdx.x * 256 + TIDX;
   Cand best{0.0, 0.0, 0, 0};
-  if (j >= 1 && j <= c->n) {
-    Cand x{0.0, 0.0, 0, 0};
-    if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, c->pw[a][j], x)) best = x;
+  if (j <= c->n) {
+    double w = 1.0;
+    if (fresh) c->pw[a][j] = 1.0;
+    else w = c->pw[a][j];
+    if (j >= 1) {
+      Cand x{0.0, 0.0, 0, 0};
+      if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, w, x)) best = x;
+    }
   }
   best = block_best<0>(best, lds);
   if (TIDX == 0) c->pp[a][blockIdx.x] = best;
@@ -1068,7 +1096,7 @@ __device__ __forceinline__ Cand wave_bcast_best(Cand b) {
 // Three dependent memory levels only: (1) the control block, (2) partials + this lane's own
 // objective-row entry, (3) what depends on the chosen q / p.  Loads of one level are issued
 // together, before the first use.
-__global__ __launch_bounds__(256) void k_fa(Ctl *c) {
+__global__ __launch_bounds__(256) void k_fa(Ctl *c, int probe) {
   __shared__ Cand lds[17];
   // level 1
   const int done = c->done, fstate = c->fstate, cur = c->curA, budget = c->budget;
@@ -1118,9 +1146,19 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c) {
     // entering column (none, no budget, or a stalled run that Bland's rule must take over: the generic
     // path continues)
     if (pc.idx == 0 || budget == 0 || stall >= stall_limit) {
-      if (lead) c->fstate = F_STOP;
+      if (lead) {
+        c->fstate = F_STOP;
+        // The pivot limit with an entering column still on offer and nothing perturbed is what the generic step would
+        // report as it stands (select_step: price, then `budget == 0` -> D_ITLIM); saying so here saves the solve a
+        // host round trip whose only purpose is that one selection.
+        if (pc.idx != 0 && budget == 0 && stall < stall_limit && !c->perturbed) {
+          c->done = D_ITLIM;
+          c->step = ST_NONE;
+        }
+      }
       return;
     }
+    if (probe) return; // last launch of a queued run: only there to notice the pivot limit, prepares nothing
     const int q = pc.idx, sdir = pc.aux;
     const int p = rc.idx, p_up = rc.aux; // p == 0: no blocking row
     // level 3
@@ -1310,7 +1348,9 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   }
   const Cand nc = wave_bcast_best<DUAL ? 1 : 0>(ncv);
   const int qn = nc.idx, sdn = nc.aux;
-  const bool tilen = (qn != 0 && (qn >> 9) == (int)blockIdx.x); // 512 columns per tile
+  // 512 columns per tile; the bootstrap launch (nothing to stream) has one block per row block, which stands in for
+  // whichever tile owns the column
+  const bool tilen = (qn != 0 && ((qn >> 9) == (int)blockIdx.x || (step == ST_NONE && gridDim.x == 1)));
   if (tilen) {
     // export the next entering column contiguously and leave this row block's ratio-test partial;
     // one lane per row, values re-read after the block's own stores
@@ -1370,6 +1410,7 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
       c->n_flips++;
       c->stall = c->stall_new;
     }
+    if (!DUAL && step == ST_NONE) c->phase = PH_PRIMAL2; // a run taken over at PH_START by k_fboot
     c->curA = nxt;
     c->nrb = (int)gridDim.y; // number of ratio-test partials this launch leaves for k_fa
   }
@@ -2197,12 +2238,12 @@ static int pick_tr(int m, int n) {
 int fused_npb(int n) { return (n + 1 + 255) / 256; }
 int fused_nrb_max(int m) { return (m + 3) / 4; }
 void launch_fboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fboot, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
-void launch_fa(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fa, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
-void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s) {
+void launch_fa(Ctl *d_ctl, int n, hipStream_t s, int probe) { hipLaunchKernelGGL(k_fa, dim3(probe ? 1 : fused_npb(n)), dim3(256), 0, s, d_ctl, probe); }
+void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s, int boot) {
   const int pairs = (n + 2) / 2;
   const int tr = pick_tr(m, n);
   const int nt = pick_nt(m, n);
-  dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
+  dim3 grid(boot ? 1 : (pairs + 255) / 256, (m + tr - 1) / tr);
 #define FB_CASE(TR_, HOT_, NT_) \
   if (tr == TR_ && g_hot == HOT_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_, 0>), grid, dim3(256), 0, s, d_ctl); return; }
   FB_CASE(16, 1, 2) FB_CASE(8, 1, 2) FB_CASE(4, 1, 2) FB_CASE(32, 1, 2) FB_CASE(16, 0, 2) FB_CASE(8, 0, 2) FB_CASE(4, 0, 2) FB_CASE(32, 0, 2) FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
