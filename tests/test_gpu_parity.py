@@ -546,3 +546,54 @@ def test_degenerate_lps_through_the_resident_tableau_kernel(gpu, orc, case):
     assert np.array_equal(g.tableau(), o.tableau())
     for u, v in zip(g.basis(), o.basis()):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("persist", [0, 1])
+def test_short_calls_taken_over_at_their_first_pivot(gpu, orc, persist):
+    """A primal call starts in the fused pipeline (k_fboot does select_step's opening feasibility check and restarts the
+    devex weights), the generic step closes each batch and k_fa reports the pivot limit itself: a run of short calls --
+    limits 1, 2, 3, 5, 8, 13, ... -- must leave the same bits as the oracle after every call, with the two-kernel path
+    (resident-tableau kernel off) and with the default choice.  The bounded columns bring flips among the first steps;
+    the last call ends on the optimum instead of the limit."""
+    gpu.set_persist(persist)
+    try:
+        for (m, n, seed) in ((96, 400, 3), (300, 700, 11)):
+            A, b, c = synth.dense_lp(m, n, seed)
+            col_b = [(capi.DB, 0.0, 0.5 + (j % 3)) if j % 4 == 0 else (capi.LO, 0.0, 0.0) for j in range(n)]
+            row_b = [(capi.UP, 0.0, float(v)) for v in b]
+            g, o = gpu.create(), orc.create()
+            for P in (g, o):
+                P.load_general(A, row_b, col_b, c, direction=capi.MAX)
+            lim, prev = 1, 1
+            for call in range(40):
+                rcs = [P.simplex(it_lim=lim) for P in (g, o)]
+                assert rcs[0] == rcs[1], (m, n, call)
+                assert_same_state(g, o, "%dx%d call %d (limit %d)" % (m, n, call, lim))
+                if rcs[0] == 0:
+                    break
+                lim, prev = lim + prev, lim
+            assert g.status == capi.OPT
+    finally:
+        gpu.set_persist(1)
+
+
+def test_first_call_not_primal_feasible_leaves_the_fused_path_alone(gpu, orc):
+    """k_fboot declines a call whose starting basis has a basic variable outside its bounds (select_step then chooses
+    between the dual simplex and phase 1) and one that has bound edits waiting in the control block."""
+    A, b, c, U = synth.dense_ilp(200, 420, seed=9, U=3)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    x = g.col_prim()
+    frac = [j + 1 for j in range(len(x)) if abs(x[j] - round(x[j])) > 1e-6]
+    assert frac
+    for P, api in ((g, gpu), (o, orc)):
+        api.set_col_bnds(P.h, frac[0], capi.DB, 0.0, float(np.floor(x[frac[0] - 1])))  # basic variable now above its bound
+        P.rc = P.simplex(it_lim=4)  # a primal-hinted call (no clone, no dual hint) with an edit waiting
+    assert g.rc == o.rc
+    assert_same_state(g, o, "after the edited call")
+    for P in (g, o):
+        P.rc = P.simplex()
+    assert g.rc == o.rc
+    assert_same_state(g, o, "finished")
