@@ -207,6 +207,14 @@ def secondary(api, with_cpu=True):
     el = time.perf_counter() - t0
     out["bnb_ilp_512x1024_coordinator"] = {"driver": "mvolps_amd.dist_bnb (1 rank)", "nodes": r2["count"], "nodes_per_s": r2["count"] / el,
                                            "pivots": r2["total_pivots"], "same_tree": treedigest.digest(r2) == treedigest.digest(r), "per_rank": 64}
+    from mvolps_amd import dist_native
+
+    t0 = time.perf_counter()
+    r3 = dist_native.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes, per_rank=64)
+    el = time.perf_counter() - t0
+    out["bnb_ilp_512x1024_native_coordinator"] = {"driver": "mvx_branchAndBound_dist (C++, 1 rank, no communicator)", "nodes": r3["count"],
+                                                  "nodes_per_s": r3["count"] / el, "pivots": r3["total_pivots"],
+                                                  "same_tree": treedigest.digest(r3) == treedigest.digest(r), "per_rank": 64}
     if with_cpu:
         out["bnb_ilp_512x1024"]["cpu_baseline"] = bnb_cpu_baseline((A, b, c, U), 0)
     fx, inst = config5_instance()
@@ -223,7 +231,7 @@ def secondary(api, with_cpu=True):
     return out
 
 
-def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes):
+def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=lambda res: None):
     """secondary.bnb_ilp_512x1024_dist (every rank calls this): the serial-equivalent node farm over the process
     group -- node LPs sharded over the ranks (bs.cpp:96-327), MAX all-reduces for the incumbent and the child bounds,
     RCCL send/recv for the children that change ranks.  Two instances, as in secondary(): the wide 512x1024 tree
@@ -275,6 +283,40 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes):
     res["per_rank"] = 64
     res["collective"] = {"backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL over xGMI)", "ranks": world,
                          "ops_per_round": "2 MAX all-reduces + send/recv of migrated node images"}
+    # The same farm through the C++ entry (mvx_branchAndBound_dist, include/mvx_dist.h) with RCCL called directly from
+    # libmvolps_rccl.so (its own communicator; torch.distributed only hands the id round).  What has been measured so
+    # far is published first: should this part stall on a node it has not met, the line still carries the rest.
+    res["native_coordinator"] = {"error": "did not finish"}
+    publish(dict(res))
+    if os.environ.get("MVX_BENCH_NO_NATIVE_DIST") != "1":
+        try:
+            from mvolps_amd import dist_native
+
+            comm = dist_native.TorchComm(device_buffers=True) if rehearsal else dist_native.RcclComm(rank, world)
+            try:
+                dist_native.branch_and_bound(synth.load_ilp(api, A, b, c, U), comm=comm, quirks=0, max_nodes=4 * world * 16, per_rank=16)  # warm-up
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rn = dist_native.branch_and_bound(synth.load_ilp(api, A, b, c, U), comm=comm, quirks=0, max_nodes=nodes, per_rank=64)
+                dist.barrier()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+                st = rn["dist"]
+                res["native_coordinator"] = {
+                    "driver": "mvx_branchAndBound_dist", "transport": "torch.distributed gloo through callbacks (rehearsal)" if rehearsal else "RCCL from C++ (libmvolps_rccl.so)",
+                    "nodes": rn["count"], "nodes_per_s": rn["count"] / el, "seconds": el, "migrated_images": st["migrated"],
+                    "migrated_share": st["migrated"] / max(1, st["children"]), "same_tree_as_python_coordinator": treedigest.digest(rn) == treedigest.digest(r_own),
+                    "same_dealing": st["migrated"] == own["migrated_images"]}
+            finally:
+                comm.close()
+        except Exception as e:
+            res["native_coordinator"] = {"error": repr(e)}
+    else:
+        res["native_coordinator"] = {"skipped": "MVX_BENCH_NO_NATIVE_DIST=1"}
     return res
 
 
@@ -446,7 +488,7 @@ def main():
             try:
                 torch.cuda.set_device(dev_index)
                 api.bind_thread()
-                box["res"] = dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, args.bnb_nodes)
+                box["res"] = dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, args.bnb_nodes, lambda part: box.__setitem__("part", part))
             except Exception as e:  # the failure modes that raise are deterministic (fixture, engine): every rank raises
                 box["res"] = {"error": repr(e)}
 
@@ -455,7 +497,8 @@ def main():
         th.join(float(os.environ.get("MVX_BENCH_DIST_DEADLINE", "240")))
         if th.is_alive():
             leg_hung = True
-            dist_leg = {"error": "timed out after %s s (a rank stalled in a collective); headline unaffected" % os.environ.get("MVX_BENCH_DIST_DEADLINE", "240")}
+            dist_leg = dict(box.get("part") or {})
+            dist_leg["error"] = "timed out after %s s (a rank stalled in a collective); headline unaffected" % os.environ.get("MVX_BENCH_DIST_DEADLINE", "240")
         else:
             dist_leg = box.get("res")
 

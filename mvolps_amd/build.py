@@ -7,9 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmvolps_amd.so")
+RCCL_LIB = os.path.join(LIBDIR, "libmvolps_rccl.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp", "bnb.cpp", "io.cpp"]
+SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp", "bnb.cpp", "bnb_dist.cpp", "io.cpp"]
 BINDIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BINDIR, "mvolps")
 # -ffp-contract=off: fma() only where written, on host and device alike (bit-exact parity
@@ -41,6 +42,15 @@ def build(force=False, verbose=False):
         objs.append(op)
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    # RCCL transport of the multi-GPU entry (include/mvx_dist.h): its own small library, so that the engine library
+    # itself does not depend on librccl
+    rccl_src = os.path.join(CSRC, "comm_rccl.cpp")
+    if force or _stale(RCCL_LIB, [rccl_src] + hdrs):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-x", "hip", rccl_src, "-o", RCCL_LIB,
+               "-L/opt/rocm/lib", "-lrccl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

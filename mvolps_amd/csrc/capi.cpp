@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "engine.hpp"
+#include "../../include/mvx_dist.h"
 
 using mvx::RowPtr;
 
@@ -463,5 +464,16 @@ double mvx_last_solve_ms(const mvx_prob *P) { return P->last_ms; }
 void mvx_sync(void) { mvx::sync_stream(); }
 int mvx_last_error(void) { return mvx::take_last_error(); }
 int mvx_bind_thread(void) { return mvx::bind_thread(); }
+
+// ---- include/mvx_dist.h: how a node travels between ranks, for the gfx950 engine
+void *mvx_image_alloc(size_t bytes) { return mvx::engine_image_alloc(bytes); }
+void mvx_image_free(void *buf) { mvx::engine_image_free(buf); }
+static long long img_pack_size(const void *P, const void *base) { return mvx_pack_size_from((const mvx_prob *)P, (const mvx_prob *)base); }
+static int img_pack(const void *P, const void *base, void *buf) { return mvx_pack_from((const mvx_prob *)P, (const mvx_prob *)base, buf); }
+static int img_unpack(void *dst, const void *base, const void *buf) { return mvx_unpack((mvx_prob *)dst, (const mvx_prob *)base, buf); }
+const mvx_image_api *mvx_hip_image_api(void) {
+  static const mvx_image_api t = {img_pack_size, img_pack, img_unpack, mvx_image_alloc, mvx_image_free};
+  return &t;
+}
 
 } // extern "C"

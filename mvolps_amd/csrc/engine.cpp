@@ -1940,6 +1940,21 @@ int engine_pack(const mvx_prob *P, int m_base, void *dev_buf) {
   return 0;
 }
 
+// buffers for node images (mvx_image_api): plain device allocations on the bound device
+void *engine_image_alloc(size_t bytes) {
+  Context &c = ctx();
+  if (hipSetDevice(c.dev) != hipSuccess) return nullptr;
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void engine_image_free(void *p) {
+  if (p) (void)hipFree(p);
+}
+
 // dst already holds a copy of the receiver's root MODEL (rows 1..m_base, objective, kinds); the appended rows,
 // bounds, basis and tableau come from the image
 int engine_unpack(mvx_prob *dst, const void *dev_buf) {

@@ -35,6 +35,8 @@ int engine_gmi_cuts(const mvx_prob *P, int mode, const int *cols, int count, dou
 long long engine_pack_size(const mvx_prob *P, int m_base);
 int engine_pack(const mvx_prob *P, int m_base, void *dev_buf);
 int engine_unpack(mvx_prob *dst, const void *dev_buf);
+void *engine_image_alloc(size_t bytes);
+void engine_image_free(void *p);
 void tuning(int tr, int hot, int nt);
 void set_stall_limit(int limit);
 void set_persist(int mode);

@@ -116,3 +116,56 @@ def run_nccl_world1(case, kw, outdir, port=None):
     port = port or (31500 + (os.getpid() % 2000))
     mp.spawn(_nccl_world1, args=(port, outdir, case, kw), nprocs=1, join=True)
     return json.load(open(os.path.join(outdir, "nccl.json")))
+
+
+# ---- the C++ coordinator (mvx_branchAndBound_dist) behind the same harness
+def oracle_tables():
+    """(api, lp table, image table) of the oracle library: host buffers from libc."""
+    from mvolps_amd import bnb, dist_native
+    from oracle import oracle
+
+    api = oracle.api()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    return api, bnb.table_from(api), dist_native.image_api_from(api, libc.malloc, libc.free)
+
+
+def _native_worker(rank, world, port, outdir, case, kw, use_gpu):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import torch.distributed as dist
+
+    from mvolps_amd import dist_native
+    from tests import lpgen
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        if use_gpu:
+            import mvolps_amd
+
+            mvolps_amd.require_device()
+            api, table, image = mvolps_amd.api(), None, None  # the engine's own tables; both ranks share cuda:0
+            api.set_device(0)
+            torch.cuda.set_device(0)
+            comm = dist_native.TorchComm(device_buffers=True)  # gloo moves host copies of the device images
+        else:
+            api, table, image = oracle_tables()
+            comm = dist_native.TorchComm()
+        root = lpgen.load_case(api, tuple(case))
+        res = dist_native.branch_and_bound(root, comm=comm, table=table, image=image, **kw)
+        with open(os.path.join(outdir, "rank%d.json" % rank), "w") as f:
+            json.dump(res, f)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_world_native(world, case, kw, outdir, use_gpu=False, port=None):
+    import torch.multiprocessing as mp
+
+    port = port or (33500 + (os.getpid() % 2000))
+    mp.spawn(_native_worker, args=(world, port, outdir, case, kw, use_gpu), nprocs=world, join=True)
+    return [json.load(open(os.path.join(outdir, "rank%d.json" % r))) for r in range(world)]

@@ -1,0 +1,97 @@
+"""CPU, world_size 2 over gloo: the C++ multi-rank entry (mvx_branchAndBound_dist, include/mvx_dist.h) must reproduce
+the serial driver's tree, decisions and incumbent exactly (serial equivalence) -- and deal the
+children exactly as the Python coordinator of the same algorithm does (same migration counts)."""
+import json
+
+import pytest
+
+from mvolps_amd import bnb, dist_native, synth
+
+from . import dist_helpers, lpgen
+from .test_dist_bnb import assert_same, canon
+
+
+@pytest.mark.parametrize("quirks,max_nodes", [(0, 0), (1, 300)])
+@pytest.mark.parametrize("per_rank", [1, 3])
+def test_world2_matches_serial(orc, tmp_path, quirks, max_nodes, per_rank):
+    case = (8, 16, 3, 2)
+    A, b, c, U = synth.dense_ilp(*case)
+    serial = canon(bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=quirks, max_nodes=max_nodes, table=bnb.table_from(orc)))
+    res = dist_helpers.run_world_native(2, case, dict(quirks=quirks, max_nodes=max_nodes, per_rank=per_rank), str(tmp_path))
+    assert_same(res[0], res[1])  # every rank ends with the same replicated result
+    assert_same(res[0], serial)
+    assert serial["count"] > 20
+
+
+def test_world2_minimisation_problem(orc, tmp_path):
+    case = ("setcover", 40, 60, 3)
+    serial = canon(bnb.branch_and_bound(lpgen.load_case(orc, case), quirks=0, table=bnb.table_from(orc)))
+    res = dist_helpers.run_world_native(2, case, dict(quirks=0, per_rank=2), str(tmp_path))
+    assert_same(res[0], res[1])
+    assert_same(res[0], serial)
+    assert abs(serial["best_lower"] - 22.0) < 1e-9
+
+
+def test_one_rank_without_a_communicator_is_the_serial_driver(orc):
+    api, table, image = dist_helpers.oracle_tables()
+    A, b, c, U = synth.dense_ilp(6, 12, 2, 3)
+    for vs in (0, 1, 2):
+        got = canon(dist_native.branch_and_bound(lpgen.load_ilp(api, A, b, c, U), table=table, image=image, var_strat=vs, quirks=0, per_rank=4))
+        ref = canon(bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), var_strat=vs, quirks=0, table=bnb.table_from(orc)))
+        assert_same(got, ref)
+    case = ("setcover", 30, 40, 2)  # integral at the root (repaired mode keeps the solution, bs.cpp:144-149 drops it)
+    got = canon(dist_native.branch_and_bound(lpgen.load_case(api, case), table=table, image=image, quirks=0))
+    ref = canon(bnb.branch_and_bound(lpgen.load_case(orc, case), quirks=0, table=bnb.table_from(orc)))
+    assert_same(got, ref)
+    assert got["count"] == 0 and got["has_incumbent"] and got["best_lower"] == 33.0
+
+
+def test_best_bound_order_is_refused(orc):
+    api, table, image = dist_helpers.oracle_tables()
+    A, b, c, U = synth.dense_ilp(6, 12, 2, 3)
+    import ctypes as C
+
+    L = dist_native._lib()
+    pr = bnb.make_params(node_strat=1)
+    res, st = bnb.BnbResult(), dist_native.DistStats()
+    rc = L.mvx_branchAndBound_dist(C.cast(C.pointer(table), C.c_void_p), C.cast(C.pointer(image), C.c_void_p), lpgen.load_ilp(api, A, b, c, U).h,
+                                   C.byref(pr), None, None, C.byref(res), C.byref(st))
+    assert rc != 0
+
+
+@pytest.mark.parametrize("kw", [dict(quirks=1, cut_strat=1, max_nodes=300), dict(quirks=0, cut_strat=1), dict(quirks=0, cut_strat=1, cut_select=1, cut_chance=0.4)],
+                         ids=["bugcompat", "repaired", "efficacy"])
+def test_world2_with_gmi_cuts_matches_serial(orc, tmp_path, kw):
+    case = (10, 20, 4, 3)
+    A, b, c, U = synth.dense_ilp(*case)
+    serial = canon(bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), table=bnb.table_from(orc), **kw))
+    res = dist_helpers.run_world_native(2, case, dict(per_rank=2, **kw), str(tmp_path))
+    assert_same(res[0], res[1])
+    assert_same(res[0], serial)
+    assert serial["count"] > 20 and res[0]["dist"]["migrated"] > 0
+
+
+def test_same_dealing_as_the_python_coordinator(orc, tmp_path):
+    """Ownership only decides the traffic; the C++ entry places every child where dist_bnb.py does."""
+    case = (16, 32, 5, 2)
+    kw = dict(quirks=0, per_rank=16)
+    for deal in ("owner", "roundrobin"):
+        nat = dist_helpers.run_world_native(2, case, dict(deal=deal, **kw), str(tmp_path))[0]
+        py = dist_helpers.run_world(2, case, dict(deal=deal, **kw), str(tmp_path))[0]
+        assert_same(nat, py)
+        for k in ("children", "migrated", "migrated_bytes", "rounds"):
+            assert nat["dist"][k] == py["dist"][k], (deal, k)
+    assert nat["dist"]["children"] > 4000
+
+
+def test_world2_on_the_config5_instance(orc, tmp_path):
+    import os
+
+    from mvolps_amd import treedigest
+
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5.json")))
+    case = (fx["m"], fx["n"], fx["seed"], fx["U"], fx["cap"])
+    res = dist_helpers.run_world_native(2, case, dict(quirks=0, max_nodes=200, per_rank=8), str(tmp_path))
+    assert_same(res[0], res[1])
+    assert treedigest.digest(res[0]) == fx["prefix"]["200"]["sha256"]
+    assert res[0]["total_pivots"] == fx["prefix"]["200"]["pivots"]
