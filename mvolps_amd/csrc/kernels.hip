@@ -1047,11 +1047,21 @@ __global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
     const double tol = c->tol_bnd;
     const double *T = c->T, *blb = c->blb, *bub = c->bub;
     int bad = 0;
-    for (int i = 1 + TIDX; i <= m; i += 256) {
-      const double beta = T[(size_t)i * ld];
-      const double lb = blb[i], ub = bub[i];
-      if (lb > -INFINITY && beta < lb - tol * (1.0 + fabs(lb))) bad = 1;
-      if (ub < INFINITY && beta > ub + tol * (1.0 + fabs(ub))) bad = 1;
+    for (int i0 = 1 + TIDX; i0 <= m; i0 += 256 * 8) { // eight strided loads in flight per lane
+      double beta[8], lb[8], ub[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + 256 * u;
+        const bool in = (i <= m);
+        beta[u] = in ? T[(size_t)i * ld] : 0.0;
+        lb[u] = in ? blb[i] : -INFINITY;
+        ub[u] = in ? bub[i] : INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (lb[u] > -INFINITY && beta[u] < lb[u] - tol * (1.0 + fabs(lb[u]))) bad = 1;
+        if (ub[u] < INFINITY && beta[u] > ub[u] + tol * (1.0 + fabs(ub[u]))) bad = 1;
+      }
     }
     if (__syncthreads_or(bad)) { // not primal feasible: the generic step decides between the dual simplex and phase 1
       if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
