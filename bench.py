@@ -457,19 +457,22 @@ def main():
         # the queued-ahead no-op launches after the limit are a few microseconds each
         k_ms = api.profile_update_ms()
         k_n = api.profile_update_launches()
-        if pivots > 0 and k_ms > 0:
-            avg_ms = k_ms / pivots
+        if pivots > 0 and k_ms > 0 and k_n > 0:
+            # one bulk launch reads and writes the tableau once, whether it applies one pivot or a chain of them
+            avg_ms = k_ms / k_n
             achieved = bytes_per_pivot(m, n) / (avg_ms * 1e-3) / 1e9
             roof = {
                 "bound": "hbm",
-                "kernel": "k_fb (streamed Gauss-Jordan rank-1 update)",
+                "kernel": "k_fbc / k_fb (streamed Gauss-Jordan update, one pass over the tableau per launch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(m, n),
                 "avg_launch_us": avg_ms * 1e3,
-                "launches_timed": pivots,
+                "launches_timed": k_n,
+                "pivots_timed": pivots,
+                "pivots_per_launch": pivots / k_n,
                 "bytes_per_launch": bytes_per_pivot(m, n),
             }
 
@@ -505,6 +508,7 @@ def main():
     out = None
     if rank == 0:
         value = world * args.steps / el_max
+        ppl = roof["pivots_per_launch"] if roof else 1.0
         out = {
             "metric": "simplex_pivots_per_s",
             "value": value,
@@ -522,10 +526,15 @@ def main():
                 "workload": "dense LP m=%d n=%d fp64, splitmix64 seed %d+rank, primal simplex pivots on the (m+1)x(n+1) tableau" % (m, n, args.seed),
                 "m": m,
                 "n": n,
-                "bytes_per_pivot": bytes_per_pivot(m, n),
+                # one pass over the tableau (read + write every entry) applies `pivots_per_pass` pivots: the chained
+                # path chooses the pivots after the first from O(m+n) slices, so the bytes a pivot needs are the pass
+                # divided by the chain length the run actually reached
+                "bytes_per_pass": bytes_per_pivot(m, n),
+                "pivots_per_pass": ppl,
+                "bytes_per_pivot": bytes_per_pivot(m, n) / ppl,
                 "parallelism": "independent LP per GPU (x%d)" % world,
             },
-            "pivot_roofline_frac": (args.steps / el_max) * bytes_per_pivot(m, n) / 1e9 / HBM_PEAK_GBS,
+            "pivot_roofline_frac": (args.steps / el_max) * (bytes_per_pivot(m, n) / ppl) / 1e9 / HBM_PEAK_GBS,
             "device_ms_per_step": device_ms / args.steps,
             "roofline": roof,
             "collective": None if dist is None else {"backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL over xGMI)",

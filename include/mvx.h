@@ -198,6 +198,9 @@ double mvx_row_residual(const mvx_prob *P);
    run of pivots): 1 on, 0 off, -1 back to the default (on unless the environment has MVX_PERSIST=0).  Results are
    identical either way.  mvx_persist_stats: launches made / launches that aborted and were redone by the two-kernel path */
 void mvx_set_persist(int mode);
+/* Pivots one pass over the tableau applies on the fused primal path (the chained selection):
+   0 = by tableau size (default), 1 = one pivot per pass, 2..16 = chains of that length.  Results do not depend on it. */
+void mvx_set_chain(int len);
 void mvx_persist_stats(long long *launches, long long *aborts);
 /* shader-clock cycles workgroup 0 spent per phase of the resident-tableau loop, summed over launches: propose, gather,
    read, apply; out5[4] = pivots */

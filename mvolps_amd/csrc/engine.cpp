@@ -50,6 +50,9 @@ int fused_nrb_max(int m);
 void launch_fboot(Ctl *, int n, hipStream_t);
 void launch_fa(Ctl *, int n, hipStream_t, int probe = 0);
 void launch_fb(Ctl *, int m, int n, hipStream_t, int boot = 0);
+void launch_fc(Ctl *, int m, int n, int k, hipStream_t);
+bool chain_supported(int m, int n);
+void launch_fbc(Ctl *, int m, int n, hipStream_t);
 void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
@@ -95,6 +98,8 @@ struct SolveCtx {
   int *d_p1list = nullptr; // phase 1: rows whose infeasibility sign changed
   int *d_tflag = nullptr;  // tableau refresh: target non-basic status by variable number
   double *d_pw[2] = {nullptr, nullptr}; // primal devex weights by column, two sets (fused path ping-pong)
+  double *d_srowk[KCH] = {}, *d_colqk[KCH] = {}; // chained primal path: scaled pivot rows / pivot columns of steps 1..
+  Cand *d_rpc = nullptr;
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
   unsigned char *d_stage = nullptr, *h_stage = nullptr;
@@ -267,6 +272,12 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_p1l = carve((size_t)(mc + 2) * 4);
   size_t o_pw0 = carve((size_t)l * 8), o_pw1 = carve((size_t)l * 8);
   size_t o_tf = carve((size_t)(mc + l + 1) * 4);
+  size_t o_sk[KCH], o_ck[KCH];
+  size_t o_rpc = carve((size_t)((mc + 255) / 256 + 1) * sizeof(Cand));
+  for (int k = 1; k < KCH; k++) {
+    o_sk[k] = carve((size_t)l * 8);
+    o_ck[k] = carve((size_t)(mc + 1) * 8);
+  }
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -292,6 +303,11 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_pw[0] = (double *)(b + o_pw0);
   sc.d_pw[1] = (double *)(b + o_pw1);
   sc.d_tflag = (int *)(b + o_tf);
+  sc.d_rpc = (Cand *)(b + o_rpc);
+  for (int k = 1; k < KCH; k++) {
+    sc.d_srowk[k] = (double *)(b + o_sk[k]);
+    sc.d_colqk[k] = (double *)(b + o_ck[k]);
+  }
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
@@ -528,6 +544,25 @@ static inline void var_bounds(const mvx_prob *P, int k, double *lb, double *ub) 
   }
 }
 
+// Pivots per bulk launch of the chained primal path.  A chained step costs two small launches (~16-20 us, growing
+// slowly with its position in the chain), a pass over the tableau costs its bytes: the longer the pass, the longer the
+// chain that pays (scripts/chainsweep.py, profiles/r02_chain_sweep.jsonl: 16.8 MB no gain, 33 MB best at 4, 67-151 MB at
+// 8, 268 MB at 12, 537 MB at 16).  MVX_CHAIN=1 turns the chaining off, 2..KCH fixes the length.
+static int g_chain = -1;
+static int chain_length(const mvx_prob *P) {
+  if (g_chain < 0) {
+    const char *e = std::getenv("MVX_CHAIN");
+    g_chain = e ? std::max(1, std::min(KCH, std::atoi(e))) : 0;
+  }
+  if (g_chain > 0) return g_chain;
+  const size_t bytes = (size_t)(P->m + 1) * (size_t)P->ld * 8;
+  if (bytes < ((size_t)24 << 20)) return 1;
+  if (bytes < ((size_t)64 << 20)) return 4;
+  if (bytes < ((size_t)200 << 20)) return 8;
+  if (bytes < ((size_t)400 << 20)) return 12;
+  return 16;
+}
+
 static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   std::memset(h, 0, sizeof(Ctl));
   h->T = P->d_T;
@@ -549,6 +584,13 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
   h->npb = fused_npb(P->n); h->nrb = 0; // nrb is published by k_fb (its grid height)
   h->fstate = F_OFF;
+  for (int k = 1; k < KCH; k++) {
+    h->srowk[k] = sc.d_srowk[k];
+    h->colqk[k] = sc.d_colqk[k];
+  }
+  h->rpc = sc.d_rpc;
+  h->chain_max = chain_length(P);
+  h->nch = 1;
 }
 
 // the handle's pending bound edits ride in the control block of the solve that is about to start
@@ -784,7 +826,8 @@ struct SolveJob {
   bool try_fused = false;
   bool try_dfused = false;    // dual phase on a large tableau: k_dboot / k_da / k_fb<DUAL>
   bool persist_queued = false; // this batch of launches contains a k_persist launch (its abort flag is copied back)
-  int seen_steps = 0, seen_pivots = 0;
+  int seen_steps = 0, seen_pivots = 0, seen_bulk = 0;
+  int chain = 1, chain0 = 1; // pivots per bulk launch the next batch is queued for / the size rule's choice
   size_t ev_used = 0;
   bool profiled = false;
   int rc = 0;
@@ -830,6 +873,7 @@ static void job_begin(Context &c, SolveJob &J) {
   upload_ctl(sc);
   HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
+  J.chain = J.chain0 = h->chain_max;
   J.try_dfused = P->hint_dual && dual_fused_worth_it(P);
   J.profiled = c.prof && J.sc == &c.main;
   // With a pivot limit the number of pivots wanted is known: queue them in one go (up to 256) instead of
@@ -916,11 +960,19 @@ static void job_enqueue(Context &c, SolveJob &J) {
         if (depth > 0) {
           launch_fboot(sc.d_ctl, n, sc.stream);
           launch_fb(sc.d_ctl, m_grid, n, sc.stream, 1);
-          for (int k = 0; k < depth; k++) {
+          // chained path: k_fc extends the step k_fa prepared into a chain of up to `kc` pivots that ONE bulk launch
+          // applies, so `depth` pivots take depth / kc passes over the tableau when every chain fills (a chain that
+          // ends early leaves pivots for the next batch)
+          int kc = (J.chain > 1 && chain_supported(m_grid, n)) ? J.chain : 1;
+          for (int left = depth; left > 0;) {
+            const int steps = std::min(kc, left); // the last pass of a limited run chains only what the limit leaves
             launch_fa(sc.d_ctl, n, sc.stream);
+            for (int t = 1; t < steps; t++) launch_fc(sc.d_ctl, m_grid, n, t, sc.stream);
             ev();
-            launch_fb(sc.d_ctl, m_grid, n, sc.stream);
+            if (kc > 1) launch_fbc(sc.d_ctl, m_grid, n, sc.stream);
+            else launch_fb(sc.d_ctl, m_grid, n, sc.stream);
             ev();
+            left -= steps;
           }
           // a run that may end on the pivot limit: one more selection that only looks (k_fa reports the limit itself)
           if (J.parm.it_lim >= 0 && depth >= remaining) launch_fa(sc.d_ctl, n, sc.stream, 1);
@@ -1050,11 +1102,21 @@ static bool job_collect(Context &c, SolveJob &J) {
   if (J.profiled) {
     // once the solve finishes inside a batch the queued-ahead launches are no-ops; only the
     // leading launches that really stepped are timed
-    const int steps_now = snap.it_cnt + snap.n_flips;
+    const int steps_now = snap.n_bulk; // launches that stepped: one per pivot or flip, one per chain of pivots
     flush_update_events(c, std::min(J.ev_used, (size_t)2 * (size_t)(steps_now - J.seen_steps)));
     J.seen_steps = steps_now;
   }
   J.done = snap.done;
+  {
+    // chains that keep ending early (bound flips, degenerate stretches, the end of the solve) leave their queued
+    // selection launches as no-ops: follow the length the last batch actually reached
+    const int dp = snap.it_cnt - J.seen_pivots, db = snap.n_bulk - J.seen_bulk;
+    if (J.chain0 > 1 && db >= 4) {
+      if (2 * dp < J.chain * db) J.chain = std::max(1, J.chain / 2);
+      else if (10 * dp >= 9 * J.chain * db) J.chain = std::min(J.chain0, J.chain * 2);
+    }
+    J.seen_bulk = snap.n_bulk;
+  }
   J.seen_pivots = snap.it_cnt;
   J.try_fused = (snap.phase == PH_PRIMAL2) && snap.stall < snap.stall_limit; // the fused path prices by Dantzig only
   J.try_dfused = (snap.phase == PH_DUAL) && snap.stall < snap.stall_limit && dual_fused_worth_it(J.P);
@@ -2036,6 +2098,7 @@ void tuning(int tr, int hot, int nt) {
   }
 }
 
+void set_chain(int len) { g_chain = (len <= 0) ? 0 : std::min(KCH, len); } // 0: by tableau size
 void set_persist(int mode) {
   g_persist_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode); // 2: no size cap
   g_persist_broken = false;

@@ -316,6 +316,7 @@ __device__ bool dev_primal_step(const KC &k, Ctl *c, int q, int sdir, const int 
         k.nflag[q] = (sdir > 0) ? MVX_NU : MVX_NL;
         c->step = ST_FLIP;
         c->n_flips++;
+        c->n_bulk++;
         c->stall = 0;
       }
       return true;
@@ -879,6 +880,7 @@ __global__ __launch_bounds__(256) void k_update(Ctl *c) {
     c->nub[q] = kub;
     c->nflag[q] = c->leave_flag;
     c->it_cnt++;
+    c->n_bulk++;
     if (c->budget > 0) c->budget--;
   }
   const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
@@ -1200,6 +1202,8 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c, int probe) {
           c->flipflag = nf;
           c->curB = cur;
           c->stall_new = 0;
+          c->nch = 1;
+          c->ch_alive = 0;
         }
         return;
       }
@@ -1246,6 +1250,20 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c, int probe) {
       c->ent_ub = ubq;
       c->curB = cur;
       c->stall_new = (rc.k1 <= DEGEN_TOL) ? stall + 1 : 0;
+      // step 0 of a chain (k_fcc / k_fcr may append to it before the bulk launch)
+      c->nch = 1;
+      c->ch_alive = (c->chain_max > 1) ? 1 : 0;
+      c->ch_p[0] = p;
+      c->ch_q[0] = q;
+      c->ch_lf[0] = lf;
+      c->ch_piv[0] = piv;
+      c->ch_xq[0] = dev_nb_value(fq, lbq, ubq);
+      c->ch_elb[0] = lbq;
+      c->ch_eub[0] = ubq;
+      c->ch_llb[0] = plb;
+      c->ch_lub[0] = pub;
+      c->ch_s0[0] = xdiv(v - bound, piv); // lane 0 of block 0 owns column 0: v = T[p][0]
+      c->ch_stall[0] = (rc.k1 <= DEGEN_TOL) ? stall + 1 : 0;
     }
   }
 }
@@ -1255,8 +1273,7 @@ __global__ __launch_bounds__(256) void k_fa(Ctl *c, int probe) {
 // whole tiles too: spare rows are never read by anything else and are re-zeroed when a cut row
 // is appended (k_add_rows).
 template <int TR, int HOT, int NT, int DUAL>
-__global__ __launch_bounds__(256) void k_fb(Ctl *c) {
-  if (c->done != D_RUN || c->fstate != (DUAL ? F_RUN_DUAL : F_RUN)) return;
+__device__ __forceinline__ void fb_body(Ctl *c) {
   const int cur = c->curB, nxt = cur ^ 1;
   const int step = c->step;
   const int m = c->m, n = c->n, p = c->p, q = c->q;
@@ -1363,7 +1380,9 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
   const bool tilen = (qn != 0 && ((qn >> 9) == (int)blockIdx.x || (step == ST_NONE && gridDim.x == 1)));
   if (tilen) {
     // export the next entering column contiguously and leave this row block's ratio-test partial;
-    // one lane per row, values re-read after the block's own stores
+    // one lane per row, values re-read after the block's own stores (the write-through stores are inline asm, which
+    // the compiler's wait-count bookkeeping does not see: wait for them by hand before the barrier)
+    if (NT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (TIDX < 64) {
       Cand best{0.0, 0.0, 0, 0};
@@ -1413,16 +1432,371 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
       c->nub[q] = kub;
       c->nflag[q] = c->leave_flag;
       c->it_cnt++;
+      c->n_bulk++;
       if (c->budget > 0) c->budget--;
       c->stall = c->stall_new;
     } else if (step == ST_FLIP) {
       c->nflag[q] = c->flipflag;
       c->n_flips++;
+      c->n_bulk++;
       c->stall = c->stall_new;
     }
     if (!DUAL && step == ST_NONE) c->phase = PH_PRIMAL2; // a run taken over at PH_START by k_fboot
     c->curA = nxt;
     c->nrb = (int)gridDim.y; // number of ratio-test partials this launch leaves for k_fa
+  }
+}
+template <int TR, int HOT, int NT, int DUAL>
+__global__ __launch_bounds__(256) void k_fb(Ctl *c) {
+  if (c->done != D_RUN || c->fstate != (DUAL ? F_RUN_DUAL : F_RUN)) return;
+  fb_body<TR, HOT, NT, DUAL>(c);
+}
+
+// ================================================================= chained primal path
+// One pass over the tableau for up to KCH pivots.  After k_fa has prepared step 0 of a chain, k_fc (ONE workgroup)
+// chooses the following steps without the bulk update having run: everything the selection of step k reads -- the
+// entering column q_k, the basic values, the leaving row p_k -- is an O(m + n) slice of the tableau as it stands in
+// memory, carried through steps 0..k-1 entry by entry with exactly the operations the bulk update would apply
+// (`chain_apply`, the per-entry case analysis of k_fb: pivot row, pivot column, fma elsewhere).  Row 0 and the devex
+// weights are updated in place step after step, as k_fa does for step 0.  k_fbc then streams the tableau ONCE and
+// applies all the steps to every entry in registers.  Same pivots, same bits as one launch per pivot -- the traffic per
+// pivot is what changes.  A chain ends early (the remaining work is then the ordinary path's) on: pivot limit, stall
+// limit, no entering column, a bound flip, an unbounded ray.
+struct ChainStep {
+  int p, q, lf;
+  double piv, xq, s0; // s0 = srow_l[0]
+};
+
+// entry (i, j) with value v before step l -> after it; ci = column q_l entry of row i, sj = scaled pivot row entry of
+// column j (both as of step l)
+__device__ __forceinline__ double chain_apply(const ChainStep &st, int i, int j, double v, double ci, double sj) {
+  if (i == st.p) return (j == st.q) ? xdiv(1.0, st.piv) : ((j == 0) ? st.xq - sj : -sj);
+  if (j == st.q) return xdiv(ci, st.piv);
+  return fma(-ci, sj, v);
+}
+
+// Step k >= 1 of a chain takes two small multi-workgroup launches, the counterparts of what k_fb's column export and
+// k_fa do for step 0:
+//   k_fcc (one lane per row): entering column q_k = reduction of the pricing partials; column q_k and the basic values as
+//          of step k; ratio-test partial per block; the lead lane stashes what k_fcr's lanes would otherwise read from
+//          entries their neighbours overwrite (d_q, the weight of q);
+//   k_fcr (one lane per column, k_fa's shape): leaving row p_k = reduction of those partials; row p_k as of step k ->
+//          scaled pivot row, objective row and devex weights in place, pricing partials for step k+1; the lead lane
+//          appends the step to the chain.
+// Every block of a kernel reaches the same verdict on whether the chain goes on (the reduction keys are a total order),
+// and only the lead lane writes it down -- for the NEXT kernel; a block that starts late and finds the chain already
+// closed returns, as it would have decided itself.
+__device__ __forceinline__ const double *uniform_ptr(const double *p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (const double *)(((unsigned long long)hi << 32) | lo);
+}
+struct ChainView { // steps 0..k-1 as every lane needs them (one copy per block, in LDS)
+  ChainStep st[KCH];
+  double elb[KCH], eub[KCH], llb[KCH], lub[KCH];
+  const double *cq[KCH], *sr[KCH]; // pivot column / scaled pivot row of each step
+};
+// all threads of the block call; ends with a barrier
+__device__ __forceinline__ void chain_load(const Ctl *c, int k, ChainView &v) {
+  const int l = TIDX;
+  if (l < k) {
+    v.st[l] = ChainStep{c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l]};
+    v.elb[l] = c->ch_elb[l];
+    v.eub[l] = c->ch_eub[l];
+    v.llb[l] = c->ch_llb[l];
+    v.lub[l] = c->ch_lub[l];
+    v.cq[l] = (l == 0) ? c->colqx[c->curB] : c->colqk[l];
+    v.sr[l] = (l == 0) ? c->srow : c->srowk[l];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
+  __shared__ Cand lds[17];
+  __shared__ ChainView v;
+  if (c->done != D_RUN || c->fstate != F_RUN || !c->ch_alive) return;
+  const bool lead = (blockIdx.x == 0 && TIDX == 0);
+  const int cur = c->curB, nxt = cur ^ 1;
+  const int m = c->m, npb = c->npb, budget = c->budget, stall_limit = c->stall_limit;
+  const size_t ld = (size_t)c->ld;
+  const double *const T = c->T;
+  const Cand *const pp = c->pp[nxt];
+  const int stall = c->ch_stall[k - 1];
+  // entering column: reduction of the pricing partials the previous step left
+  Cand pc{0.0, 0.0, 0, 0};
+  for (int t = TIDX & 63; t < npb; t += 64) {
+    Cand x = pp[t];
+    if (cand_better<0>(x, pc)) pc = x;
+  }
+  pc = wave_bcast_best<0>(pc);
+  if (pc.idx == 0 || (budget >= 0 && budget < k + 1) || stall >= stall_limit) {
+    if (lead) c->ch_alive = 0;
+    return;
+  }
+  const int q = pc.idx, sdir = pc.aux;
+  chain_load(c, k, v);
+  double *const ck = c->colqk[k];
+  const int i = 1 + (int)blockIdx.x * 256 + TIDX;
+  Cand rb{0.0, 0.0, 0, 0};
+  if (i <= m) {
+    double a = T[(size_t)i * ld + q];
+    double beta = c->betac[cur][i];
+    double lb = c->blb[i], ub = c->bub[i];
+    for (int l = 0; l < k; l++) {
+      const double ci = v.cq[l][i];
+      a = chain_apply(v.st[l], i, q, a, ci, v.sr[l][q]);
+      beta = chain_apply(v.st[l], i, 0, beta, ci, v.st[l].s0);
+      if (v.st[l].p == i) {
+        lb = v.elb[l];
+        ub = v.eub[l];
+      }
+    }
+    ck[i] = a;
+    Cand x{0.0, 0.0, 0, 0};
+    if (ratio_row(a, sdir, beta, lb, ub, 0, c->tol_piv, i, x)) rb = x;
+  }
+  rb = block_best<1>(rb, lds);
+  if (TIDX == 0) c->rpc[blockIdx.x] = rb;
+  if (lead) {
+    // the entering variable as the earlier steps of the chain left it (bounds, status)
+    double lbq = c->nlb[q], ubq = c->nub[q];
+    int fq = c->nflag[q];
+    for (int l = 0; l < k; l++) {
+      if (v.st[l].q == q) {
+        lbq = v.llb[l];
+        ubq = v.lub[l];
+        fq = v.st[l].lf;
+      }
+    }
+    const double dq = T[q];
+    ck[0] = dq;
+    c->ch_q[k] = q;
+    c->ch_sdir[k] = sdir;
+    c->ch_elb[k] = lbq;
+    c->ch_eub[k] = ubq;
+    c->ch_fq[k] = fq;
+    c->ch_dq[k] = dq;
+    c->ch_wq[k] = c->pw[nxt][q];
+    c->ch_nrpc = (int)gridDim.x;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fcr(Ctl *c, int k) {
+  __shared__ Cand lds[17];
+  __shared__ ChainView v;
+  if (c->done != D_RUN || c->fstate != F_RUN || !c->ch_alive) return;
+  const bool lead = (blockIdx.x == 0 && TIDX == 0);
+  const int cur = c->curB, nxt = cur ^ 1;
+  const int n = c->n, nrpc = c->ch_nrpc;
+  const size_t ld = (size_t)c->ld;
+  double *const T = c->T;
+  const int q = c->ch_q[k];
+  const double lbq = c->ch_elb[k], ubq = c->ch_eub[k], dq = c->ch_dq[k], wq = c->ch_wq[k];
+  const int fq = c->ch_fq[k];
+  // leaving row: reduction of the ratio-test partials
+  Cand rc{0.0, 0.0, 0, 0};
+  for (int t = TIDX & 63; t < nrpc; t += 64) {
+    Cand x = c->rpc[t];
+    if (cand_better<1>(x, rc)) rc = x;
+  }
+  rc = wave_bcast_best<1>(rc);
+  bool stop = (rc.idx == 0); // unbounded ray: the generic path reports it
+  if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+    const double tf = ubq - lbq;
+    if (rc.idx == 0 || tf <= rc.k1) stop = true; // bound flip: the ordinary path takes it
+  }
+  if (stop) {
+    if (lead) c->ch_alive = 0;
+    return;
+  }
+  const int p = rc.idx, p_up = rc.aux;
+  chain_load(c, k, v);
+  double plb = c->blb[p], pub = c->bub[p];
+  for (int l = 0; l < k; l++)
+    if (v.st[l].p == p) {
+      plb = v.elb[l];
+      pub = v.eub[l];
+    }
+  const double piv = c->colqk[k][p];
+  const double bound = p_up ? pub : plb;
+  const int lf = dev_leave_flag(plb, pub, p_up);
+  double *const pw = c->pw[nxt];
+  double *const sk = c->srowk[k];
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  Cand best{0.0, 0.0, 0, 0};
+  double s0 = 0.0;
+  if (j <= n) {
+    double val = T[(size_t)p * ld + j];
+    for (int l = 0; l < k; l++) val = chain_apply(v.st[l], p, j, val, v.cq[l][p], v.sr[l][j]);
+    const double sj = (j == 0) ? xdiv(val - bound, piv) : xdiv(val, piv);
+    sk[j] = sj;
+    s0 = sj;
+    const double dold = T[j];
+    const double dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dold);
+    T[j] = dnew;
+    if (j >= 1) {
+      double wn;
+      if (j == q) {
+        const double cc = xdiv(wq, piv * piv);
+        wn = cc > 1.0 ? cc : 1.0;
+      } else {
+        const double cc = sj * sj * wq;
+        const double wj = pw[j];
+        wn = cc > wj ? cc : wj;
+      }
+      pw[j] = wn;
+      int f = c->nflag[j];
+      for (int l = 0; l < k; l++)
+        if (v.st[l].q == j) f = v.st[l].lf;
+      if (j == q) f = lf;
+      Cand x{0.0, 0.0, 0, 0};
+      if (price_col(f, c->sgn * dnew, c->tol_dj, j, wn, x)) best = x;
+    }
+  }
+  best = block_best<0>(best, lds);
+  if (TIDX == 0) c->pp[nxt][blockIdx.x] = best; // k_fcc of this step has consumed the partials that were here
+  if (lead) {
+    c->ch_p[k] = p;
+    c->ch_pup[k] = p_up;
+    c->ch_lf[k] = lf;
+    c->ch_piv[k] = piv;
+    c->ch_bound[k] = bound;
+    c->ch_xq[k] = dev_nb_value(fq, lbq, ubq);
+    c->ch_llb[k] = plb;
+    c->ch_lub[k] = pub;
+    c->ch_s0[k] = s0; // lane 0 of block 0 owns column 0
+    c->ch_stall[k] = (rc.k1 <= DEGEN_TOL) ? c->ch_stall[k - 1] + 1 : 0;
+    c->nch = k + 1;
+  }
+}
+
+// The bulk launch of a chain: k_fb's stream with `nch` steps applied to every entry (nch == 1: exactly k_fb).  Flips
+// and the bootstrap never chain, so they stay with k_fb; this kernel sees ST_PIVOT only.
+template <int TR, int NT>
+__global__ __launch_bounds__(256) void k_fbc(Ctl *c) {
+  if (c->done != D_RUN || c->fstate != F_RUN) return;
+  const int nch = c->nch;
+  if (nch <= 1) { // a single pivot, a bound flip, the bootstrap: k_fb's own code
+    fb_body<TR, 1, NT, 0>(c);
+    return;
+  }
+  __shared__ ChainView cv;
+  const int cur = c->curB, nxt = cur ^ 1;
+  const int m = c->m, n = c->n;
+  const size_t ld = (size_t)c->ld;
+  const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
+  const bool active = (j0 <= n);
+  const int i0 = 1 + (int)blockIdx.y * TR;
+  const bool has0 = (j0 == 0);
+  double *bnew = c->betac[nxt];
+  const int npb = c->npb;
+  const Cand *ppn = c->pp[nxt];
+  Cand ncv = ((TIDX & 63) < npb) ? ppn[TIDX & 63] : Cand{0.0, 0.0, 0, 0};
+  chain_load(c, nch, cv);
+  if (active) {
+    double *base = c->T + (size_t)i0 * ld + j0;
+    double2 v[TR];
+#pragma unroll
+    for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
+    for (int l = 0; l < nch; l++) {
+      const ChainStep st = cv.st[l];
+      const double2 s = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[l]) + j0);
+      // the step's pointers come out of LDS: make them wave-uniform by hand so that the 16 pivot-column entries of the
+      // tile are fetched by scalar loads, as k_fb's are
+      const double *cql = uniform_ptr(cv.cq[l]) + i0;
+      double ci[TR];
+#pragma unroll
+      for (int r = 0; r < TR; r++) ci[r] = cql[r];
+      const bool q0 = (j0 == st.q), q1 = (j0 + 1 == st.q);
+#pragma unroll
+      for (int r = 0; r < TR; r++) {
+        v[r].x = fma(-ci[r], s.x, v[r].x);
+        v[r].y = fma(-ci[r], s.y, v[r].y);
+      }
+      if (q0 || q1) {
+#pragma unroll
+        for (int r = 0; r < TR; r++) {
+          const double qv = xdiv(ci[r], st.piv);
+          if (q0) v[r].x = qv;
+          if (q1) v[r].y = qv;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (st.p >= i0 && st.p < i0 + TR) {
+#pragma unroll
+        for (int r = 0; r < TR; r++) {
+          if (i0 + r == st.p) {
+            v[r].x = q0 ? xdiv(1.0, st.piv) : -s.x;
+            v[r].y = q1 ? xdiv(1.0, st.piv) : -s.y;
+            if (has0) v[r].x = st.xq - s.x;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
+    if (has0) {
+#pragma unroll
+      for (int r = 0; r < TR; r++) bnew[i0 + r] = v[r].x;
+    }
+  }
+  // next entering column (0 = none: k_fa will stop)
+  for (int k = (TIDX & 63) + 64; k < npb; k += 64) {
+    Cand x = ppn[k];
+    if (cand_better<0>(x, ncv)) ncv = x;
+  }
+  const Cand nc = wave_bcast_best<0>(ncv);
+  const int qn = nc.idx, sdn = nc.aux;
+  const bool tilen = (qn != 0 && (qn >> 9) == (int)blockIdx.x);
+  if (tilen) {
+    if (NT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores above are inline asm
+    __syncthreads();
+    if (TIDX < 64) {
+      Cand best{0.0, 0.0, 0, 0};
+      const double *b0 = c->betac[cur];
+      for (int r = TIDX; r < TR; r += 64) {
+        const int i = i0 + r;
+        if (i > m) break;
+        const double a = c->T[(size_t)i * ld + qn];
+        c->colqx[nxt][i] = a;
+        double beta = b0[i], lb = c->blb[i], ub = c->bub[i];
+        for (int l = 0; l < nch; l++) {
+          beta = chain_apply(cv.st[l], i, 0, beta, cv.cq[l][i], cv.st[l].s0);
+          if (cv.st[l].p == i) {
+            lb = cv.elb[l];
+            ub = cv.eub[l];
+          }
+        }
+        Cand x{0.0, 0.0, 0, 0};
+        if (ratio_row(a, sdn, beta, lb, ub, 0, c->tol_piv, i, x)) {
+          if (cand_better<1>(x, best)) best = x;
+        }
+      }
+      best = wave_best<1>(best);
+      if (TIDX == 0) c->rp[blockIdx.y] = best;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && TIDX == 0) {
+    bnew[0] = c->T[0];
+    if (qn != 0) c->colqx[nxt][0] = c->T[qn];
+    for (int l = 0; l < nch; l++) { // the basis swaps of the chain, in order
+      const int p = cv.st[l].p, q = cv.st[l].q;
+      const int kv = c->bvar[p];
+      const double klb = c->blb[p], kub = c->bub[p];
+      c->bvar[p] = c->nvar[q];
+      c->blb[p] = c->nlb[q];
+      c->bub[p] = c->nub[q];
+      c->nvar[q] = kv;
+      c->nlb[q] = klb;
+      c->nub[q] = kub;
+      c->nflag[q] = cv.st[l].lf;
+    }
+    c->it_cnt += nch;
+    c->n_bulk++;
+    if (c->budget > 0) c->budget -= nch;
+    c->stall = c->ch_stall[nch - 1];
+    c->curA = nxt;
+    c->nrb = (int)gridDim.y;
   }
 }
 
@@ -2261,6 +2635,24 @@ void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s, int boot) {
   FB_CASE(4, 1, 0) FB_CASE(4, 0, 0) FB_CASE(4, 1, 1) FB_CASE(4, 0, 1)
 #undef FB_CASE
   std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
+}
+// step k of a chain: column kernel, then row kernel
+void launch_fc(Ctl *d_ctl, int m, int n, int k, hipStream_t s) {
+  hipLaunchKernelGGL(k_fcc, dim3((m + 255) / 256), dim3(256), 0, s, d_ctl, k);
+  hipLaunchKernelGGL(k_fcr, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl, k);
+}
+// bulk launch of a chain; returns false when the tuning in force has no chained variant (the caller then uses k_fb)
+bool chain_supported(int m, int n) { return g_hot == 1 && pick_tr(m, n) <= 16; }
+void launch_fbc(Ctl *d_ctl, int m, int n, hipStream_t s) {
+  const int pairs = (n + 2) / 2;
+  const int tr = pick_tr(m, n);
+  const int nt = pick_nt(m, n);
+  dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
+#define FBC_CASE(TR_, NT_) \
+  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fbc<TR_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
+  FBC_CASE(16, 0) FBC_CASE(16, 1) FBC_CASE(16, 2) FBC_CASE(8, 0) FBC_CASE(8, 1) FBC_CASE(8, 2) FBC_CASE(4, 0) FBC_CASE(4, 1) FBC_CASE(4, 2)
+#undef FBC_CASE
+  std::abort(); // unreachable: chain_supported() gates the call
 }
 void launch_dboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_dboot, dim3((n + DA_THREADS) / DA_THREADS), dim3(DA_THREADS), 0, s, d_ctl); }
 void launch_da(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_da, dim3((n + DA_THREADS) / DA_THREADS), dim3(DA_THREADS), 0, s, d_ctl); }

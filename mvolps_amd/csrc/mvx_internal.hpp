@@ -26,6 +26,7 @@ constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this co
 constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
 constexpr size_t WT_MIN_BYTES = (size_t)96 << 20, WT_MAX_BYTES = (size_t)272 << 20; // write-through stores in this band (pick_nt)
+constexpr int KCH = 16;          // most pivots one bulk launch of the chained primal path applies (k_fc / k_fbc)
 constexpr int DA_THREADS = 1024; // k_dboot / k_da workgroup size: the O(m) leaving-row pass is redundant per block
 constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
@@ -104,6 +105,19 @@ struct Ctl {
   double *dwx[2];
   int p_nextx[2], p_up_nextx[2];
   int npbd; // number of dual-ratio partials (k_da blocks of DA_THREADS columns)
+  // Chained primal path (k_fc / k_fbc): the pivots after the one k_fa prepared are chosen from O(m + n) slices of the
+  // tableau as it stands -- column q_k and row p_k, carried through the earlier pivots of the chain entry by entry --
+  // and ONE bulk launch applies the whole chain (each entry read and written once for up to KCH pivots).  Step 0 of a
+  // chain is the step k_fa left in the fields above; ch_*[l] describes step l >= 1 (index 0 is filled for uniform loops).
+  int chain_max, nch; // chain length allowed by the host (1 = off) / prepared for the coming bulk launch
+  int n_bulk;         // bulk launches that stepped so far in this solve (one per pivot or flip; one per chain)
+  int ch_alive, ch_nrpc; // the chain may still grow / ratio-test partials k_fcc left
+  int ch_p[KCH], ch_q[KCH], ch_pup[KCH], ch_lf[KCH], ch_stall[KCH], ch_sdir[KCH], ch_fq[KCH];
+  double ch_piv[KCH], ch_bound[KCH], ch_xq[KCH], ch_s0[KCH], ch_dq[KCH], ch_wq[KCH];
+  Cand *rpc; // [ceil(m_cap / 256)] ratio-test partials of k_fcc
+  double ch_elb[KCH], ch_eub[KCH]; // bounds of the entering variable (become row p's)
+  double ch_llb[KCH], ch_lub[KCH]; // bounds of the leaving variable (become column q's)
+  double *srowk[KCH], *colqk[KCH]; // scaled pivot row / pivot column of step l >= 1 ([0] unused: srow, colqx[curB])
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots

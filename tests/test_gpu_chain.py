@@ -1,0 +1,105 @@
+"""GPU: the chained primal path (k_fa + k_fcc/k_fcr per further step + ONE bulk launch k_fbc for the whole chain) leaves
+the same bits as the oracle, whatever the chain length: the pivots after the first are chosen from column / row slices
+carried through the earlier pivots of the chain entry by entry, so every case of that carry (pivot row, pivot column,
+the same row leaving twice, a column re-entering, bounds and status moved by the earlier swaps) has to come out as the
+bulk update would have left it.  Small LPs, resident-tableau kernel off, chain length forced."""
+import numpy as np
+import pytest
+
+from mvolps_amd import capi, synth
+
+from . import lpgen
+from .test_gpu_parity import assert_same_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def chained(gpu):
+    gpu.set_persist(0)
+    yield gpu
+    gpu.set_chain(0)
+    gpu.set_persist(1)
+
+
+@pytest.mark.parametrize("chain", [2, 5, 16])
+def test_dense_lps_full_solves(chained, orc, chain):
+    chained.set_chain(chain)
+    for (m, n, seed) in ((64, 128, 1), (100, 37, 5), (256, 512, 12345), (300, 700, 11), (512, 1024, 12345)):
+        A, b, c = synth.dense_lp(m, n, seed)
+        g, o = chained.create(), orc.create()
+        for P in (g, o):
+            P.load_dense(A, b, c)
+            assert P.simplex() == 0
+        assert_same_state(g, o, "dense %dx%d chain %d" % (m, n, chain))
+
+
+@pytest.mark.parametrize("chain", [2, 3, 16])
+def test_bounded_columns_bring_flips_into_the_chains(chained, orc, chain):
+    """Boxed columns: a chain ends where the next step is a bound flip (the ordinary path takes it), an entering column
+    may be one that left a few steps earlier (its bounds and status come from the chain's own record)."""
+    chained.set_chain(chain)
+    rng = np.random.default_rng(5)
+    for (m, n, seed) in ((96, 400, 3), (200, 300, 8), (300, 700, 11)):
+        A, b, c = synth.dense_lp(m, n, seed)
+        col_b = [(capi.DB, 0.0, float(rng.integers(1, 4)) / 2) if j % 3 else (capi.LO, 0.0, 0.0) for j in range(n)]
+        row_b = [(capi.UP, 0.0, float(v)) for v in b]
+        g, o = chained.create(), orc.create()
+        for P in (g, o):
+            P.load_general(A, row_b, col_b, c, direction=capi.MAX)
+            P.rc = P.simplex()
+        assert g.rc == o.rc
+        assert_same_state(g, o, "boxed %dx%d chain %d" % (m, n, chain))
+
+
+@pytest.mark.parametrize("chain", [2, 7, 16])
+def test_limits_that_fall_inside_a_chain(chained, orc, chain):
+    """Pivot limits 1, 2, 3, 5, 8, ...: the last chain of a call holds only what the limit leaves."""
+    chained.set_chain(chain)
+    A, b, c = synth.dense_lp(200, 500, 21)
+    g, o = chained.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+    lim, prev = 1, 1
+    for call in range(40):
+        rcs = [P.simplex(it_lim=lim) for P in (g, o)]
+        assert rcs[0] == rcs[1]
+        assert_same_state(g, o, "call %d limit %d chain %d" % (call, lim, chain))
+        if rcs[0] == 0:
+            break
+        lim, prev = lim + prev, lim
+    assert g.status == capi.OPT
+
+
+@pytest.mark.parametrize("chain", [2, 16])
+def test_degenerate_lps_and_stalling(chained, orc, chain):
+    """Degenerate vertices: stall counters run through the chain (a chain ends at the stall limit; Bland's rule and the
+    perturbation stay with the generic path), the same row may leave twice within one chain."""
+    chained.set_chain(chain)
+    for case in ((358, 124, 41004, 0.8), (288, 252, 41002, 0.8), (314, 433, 41000, 0.95)):
+        m, n, seed, dens = case
+        A, b, c = lpgen.degenerate_lp(m, n, seed, frac0=dens)
+        g, o = lpgen.load_degenerate(chained, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+        for P in (g, o):
+            P.rc = P.simplex()
+        assert g.rc == o.rc
+        assert g.pert_cnt == o.pert_cnt and g.bland_cnt == o.bland_cnt
+        assert_same_state(g, o, "degenerate %s chain %d" % (case, chain))
+    for name, (A, b, c) in lpgen.CYCLING.items():
+        A, b, c = (np.array(v, float) for v in (A, b, c))
+        g, o = chained.create(), orc.create()
+        for P in (g, o):
+            P.load_dense(A, b, c)
+            assert P.simplex() == 0
+        assert_same_state(g, o, name)
+
+
+def test_chain_length_by_size_is_the_default(gpu, orc):
+    """Default setting (length by tableau size): 1024x4096 is in the band that chains four pivots per pass."""
+    gpu.set_chain(0)
+    A, b, c = synth.dense_lp(1024, 4096, 7)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+        assert P.simplex(it_lim=150) == capi.EITLIM
+    assert_same_state(g, o, "1024x4096, 150 pivots")
