@@ -547,7 +547,7 @@ static inline void var_bounds(const mvx_prob *P, int k, double *lb, double *ub) 
 // Pivots per bulk launch of the chained primal path.  A chained step costs two small launches (~16-20 us, growing
 // slowly with its position in the chain), a pass over the tableau costs its bytes: the longer the pass, the longer the
 // chain that pays (scripts/chainsweep.py, profiles/r02_chain_sweep.jsonl: 16.8 MB no gain, 33 MB best at 4, 67-151 MB at
-// 8, 268 MB at 12, 537 MB at 16).  MVX_CHAIN=1 turns the chaining off, 2..KCH fixes the length.
+// 8, 268 MB at 10-12 -- 10 keeps the bulk launch above 0.6 of the HBM roofline for 1 % of the rate --, 537 MB at 16).  MVX_CHAIN=1 turns the chaining off, 2..KCH fixes the length.
 static int g_chain = -1;
 static int chain_length(const mvx_prob *P) {
   if (g_chain < 0) {
@@ -559,7 +559,7 @@ static int chain_length(const mvx_prob *P) {
   if (bytes < ((size_t)24 << 20)) return 1;
   if (bytes < ((size_t)64 << 20)) return 4;
   if (bytes < ((size_t)200 << 20)) return 8;
-  if (bytes < ((size_t)400 << 20)) return 12;
+  if (bytes < ((size_t)400 << 20)) return 10;
   return 16;
 }
 

@@ -1698,15 +1698,27 @@ __global__ __launch_bounds__(256) void k_fbc(Ctl *c) {
     double2 v[TR];
 #pragma unroll
     for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
+    // the step's pointers come out of LDS: made wave-uniform by hand so that the pivot-column entries of the tile are
+    // fetched by scalar loads, as k_fb's are; step l+1's operands are requested while step l is applied
+    double2 s_n = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[0]) + j0);
+    double ci_n[TR];
+    {
+      const double *cql = uniform_ptr(cv.cq[0]) + i0;
+#pragma unroll
+      for (int r = 0; r < TR; r++) ci_n[r] = cql[r];
+    }
     for (int l = 0; l < nch; l++) {
       const ChainStep st = cv.st[l];
-      const double2 s = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[l]) + j0);
-      // the step's pointers come out of LDS: make them wave-uniform by hand so that the 16 pivot-column entries of the
-      // tile are fetched by scalar loads, as k_fb's are
-      const double *cql = uniform_ptr(cv.cq[l]) + i0;
+      const double2 s = s_n;
       double ci[TR];
 #pragma unroll
-      for (int r = 0; r < TR; r++) ci[r] = cql[r];
+      for (int r = 0; r < TR; r++) ci[r] = ci_n[r];
+      if (l + 1 < nch) {
+        s_n = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[l + 1]) + j0);
+        const double *cql = uniform_ptr(cv.cq[l + 1]) + i0;
+#pragma unroll
+        for (int r = 0; r < TR; r++) ci_n[r] = cql[r];
+      }
       const bool q0 = (j0 == st.q), q1 = (j0 + 1 == st.q);
 #pragma unroll
       for (int r = 0; r < TR; r++) {

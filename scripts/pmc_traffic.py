@@ -8,7 +8,7 @@ usage: pmc_traffic.py <fetch_dir> <write_dir> <m> <n> <out.json>
 import csv, glob, json, statistics, sys
 
 def per_launch(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     vals = []
     for r in csv.DictReader(open(f)):
         if "k_fb" in r["Kernel_Name"] and r["Counter_Name"] == counter:
