@@ -201,6 +201,10 @@ void mvx_set_persist(int mode);
 /* Pivots one pass over the tableau applies on the fused primal path (the chained selection):
    0 = by tableau size (default), 1 = one pivot per pass, 2..16 = chains of that length.  Results do not depend on it. */
 void mvx_set_chain(int len);
+/* the same for the dual simplex steps of the generic path (every warm-started B&B child): 0 = default (8 for launches
+   shared by 32 or more node LPs and for tableaux of 16 MB and more, else 4), 1 = off, 2..8 = dual pivots one update
+   pass applies */
+void mvx_set_dual_chain(int len);
 void mvx_persist_stats(long long *launches, long long *aborts);
 /* shader-clock cycles workgroup 0 spent per phase of the resident-tableau loop, summed over launches: propose, gather,
    read, apply; out5[4] = pivots */

@@ -454,6 +454,7 @@ int mvx_get_refresh_cnt(const mvx_prob *P) { return P->refresh_cnt; }
 double mvx_row_residual(const mvx_prob *P) { return mvx::row_residual(P); }
 void mvx_set_persist(int mode) { mvx::set_persist(mode); }
 void mvx_set_chain(int len) { mvx::set_chain(len); }
+void mvx_set_dual_chain(int len) { mvx::set_dual_chain(len); }
 void mvx_persist_stats(long long *launches, long long *aborts) { mvx::persist_stats(launches, aborts); }
 void mvx_persist_cycles(unsigned long long *out5) { mvx::persist_cycles(out5); }
 void mvx_set_batch_slots(int slots) { mvx::set_batch_slots(slots); }

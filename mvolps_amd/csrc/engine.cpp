@@ -58,7 +58,7 @@ void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
 void launch_select(Ctl *, hipStream_t, int slots = 1);
 void launch_select_queue(Ctl *, const BatchQueue &q, hipStream_t, int slots);
-void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1);
+void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1, int chained = 0);
 void launch_p1_head(Ctl *, hipStream_t);
 void launch_p1_select(Ctl *, hipStream_t);
 void launch_p1_fix(Ctl *, int n, hipStream_t);
@@ -563,6 +563,21 @@ static int chain_length(const mvx_prob *P) {
   return 16;
 }
 
+// Dual pivots one k_update applies (dual_chain; MVX_DCHAIN=1 turns it off, 2..8 fixes the length).  The chain is built
+// inside k_select at a few microseconds per step; what it saves is the k_update pass and the two launch boundaries of
+// every step it absorbs.  Where the pass is the cost -- a launch shared by many node LPs, or one large tableau -- the
+// longest chain pays (wide 512x1024 tree: 9.1 k nodes/s unchained, 14.8 k at 4, 18.9 k at 8); where a few small
+// tableaux wait on each other's longest solve, 4 is the optimum (config-5 tree: 3.30 k, 4.40 k at 4, 4.22 k at 8).
+static int g_dchain = -1;
+static int dual_chain_length(bool wide) {
+  if (g_dchain < 0) {
+    const char *e = std::getenv("MVX_DCHAIN");
+    g_dchain = e ? std::max(1, std::min(DCH_MAX, std::atoi(e))) : 0;
+  }
+  if (g_dchain > 0) return g_dchain;
+  return wide ? 8 : 4;
+}
+
 static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   std::memset(h, 0, sizeof(Ctl));
   h->T = P->d_T;
@@ -590,6 +605,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   }
   h->rpc = sc.d_rpc;
   h->chain_max = chain_length(P);
+  h->dchain_max = dual_chain_length((size_t)(P->m + 1) * (size_t)P->ld * 8 >= ((size_t)16 << 20));
   h->nch = 1;
 }
 
@@ -932,7 +948,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
         // launch whose workgroups do not all become resident in time aborts mid-step, and the backup is what the
         // two-kernel path then carries on from.
         launch_select(sc.d_ctl, sc.stream);
-        launch_update(sc.d_ctl, m_grid, n, sc.stream);
+        launch_update(sc.d_ctl, m_grid, n, sc.stream, 1, 1);
         HIPCHECK(hipMemcpyAsync(sc.p_backup, P->slab, P->slab_bytes, hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_pctl, sc.d_ctl, sizeof(Ctl), hipMemcpyDeviceToDevice, sc.stream));
         HIPCHECK(hipMemcpyAsync(sc.d_ppw, sc.d_pw[0], (size_t)P->ld * 8, hipMemcpyDeviceToDevice, sc.stream));
@@ -945,7 +961,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
           g_persist_launches++;
           // what the run ended on (optimum, unbounded ray, stall, pivot limit) is settled by one generic step
           launch_select(sc.d_ctl, sc.stream);
-          launch_update(sc.d_ctl, m_grid, n, sc.stream);
+          launch_update(sc.d_ctl, m_grid, n, sc.stream, 1, 1);
         } else {
           g_persist_broken = true;
         }
@@ -979,7 +995,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
         }
         launch_select(sc.d_ctl, sc.stream);
         if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic], sc.stream));
-        launch_update(sc.d_ctl, m_grid, n, sc.stream);
+        launch_update(sc.d_ctl, m_grid, n, sc.stream, 1, 1);
         if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic + 1], sc.stream));
       }
     } else if (J.try_dfused) {
@@ -987,7 +1003,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
       // entered); if it is the dual simplex, the fused pair k_da / k_fb<DUAL> takes over, otherwise its launches
       // return at once
       launch_select(sc.d_ctl, sc.stream);
-      launch_update(sc.d_ctl, m_grid, n, sc.stream);
+      launch_update(sc.d_ctl, m_grid, n, sc.stream, 1, 1);
       if (depth > 1) {
         launch_dboot(sc.d_ctl, n, sc.stream);
         launch_db(sc.d_ctl, m_grid, n, sc.stream);
@@ -1000,7 +1016,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
       for (int k = 0; k < depth; k++) {
         launch_select(sc.d_ctl, sc.stream);
         ev();
-        launch_update(sc.d_ctl, m_grid, n, sc.stream);
+        launch_update(sc.d_ctl, m_grid, n, sc.stream, 1, 1);
         ev();
       }
     }
@@ -1356,7 +1372,8 @@ static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
   HIPCHECK(hipHostMalloc((void **)&bc.h_cnt, sizeof(int) * 4));
   const size_t s_row = align_up((size_t)(bc.m_cap + 1) * 8, 256), s_col = align_up((size_t)bc.ld * 8, 256);
   const size_t s_var = align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256);
-  bc.scratch_stride = s_row + s_col + 2 * s_var + s_row + s_col;
+  const size_t s_chain = (size_t)(DCH_MAX - 1) * (s_row + s_col);
+  bc.scratch_stride = s_row + s_col + 2 * s_var + s_row + s_col + s_chain;
   HIPCHECK(hipMalloc((void **)&bc.scratch, bc.scratch_stride * bc.slots));
   HIPCHECK(hipMemsetAsync(bc.scratch, 0, bc.scratch_stride * bc.slots, bc.stream));
   for (int k = 0; k < bc.slots; k++) {
@@ -1368,6 +1385,9 @@ static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
     sp.oub = (double *)(sb + s_row + s_col + s_var);
     sp.dw = (double *)(sb + s_row + s_col + 2 * s_var);
     sp.pw = (double *)(sb + s_row + s_col + 2 * s_var + s_row); // generic path only: one set of primal weights
+    sp.chain = (double *)(sb + s_row + s_col + 2 * s_var + s_row + s_col);
+    sp.chain_col = s_row;
+    sp.chain_stride = s_row + s_col;
   }
   HIPCHECK(hipMemcpyAsync(bc.d_sp, bc.h_sp, sizeof(SlotScratch) * bc.slots, hipMemcpyHostToDevice, bc.stream));
   bc.stage_stride = stage_size(bc.m_cap, bc.ld);
@@ -1382,7 +1402,7 @@ static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
 }
 
 // control block of one job; the slot that pulls it points it at its own scratch (k_select)
-static void batch_fill_job(Ctl *h, mvx_prob *P, const mvx_smcp &parm) {
+static void batch_fill_job(Ctl *h, mvx_prob *P, const mvx_smcp &parm, int njobs) {
   std::memset(h, 0, sizeof(Ctl));
   h->T = P->d_T;
   h->bvar = P->d_bvar; h->blb = P->d_blb; h->bub = P->d_bub;
@@ -1394,6 +1414,8 @@ static void batch_fill_job(Ctl *h, mvx_prob *P, const mvx_smcp &parm) {
   h->stall = 0; h->stall_limit = g_stall_limit > 0 ? g_stall_limit : 64 + (P->m + P->n) / 8;
   h->fstate = F_OFF;
   h->job = -1;
+  h->nch = 1;
+  h->dchain_max = dual_chain_length(njobs >= 32);
   take_edits(P, h);
 }
 
@@ -1492,7 +1514,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   ensure_batch(bc, K, njobs, m_cap, ld);
   // edits queued on the main stream (bound changes, clones) must be visible to the batch stream
   HIPCHECK(hipStreamSynchronize(c.main.stream));
-  for (int j = 0; j < njobs; j++) batch_fill_job(&bc.h_jobs[j], probs[pending[(size_t)j]], parm);
+  for (int j = 0; j < njobs; j++) batch_fill_job(&bc.h_jobs[j], probs[pending[(size_t)j]], parm, njobs);
   bc.h_cnt[0] = bc.h_cnt[1] = 0;
   HIPCHECK(hipMemcpyAsync(bc.d_jobs, bc.h_jobs, sizeof(Ctl) * (size_t)njobs, hipMemcpyHostToDevice, bc.stream));
   HIPCHECK(hipMemcpyAsync(bc.d_ctl, bc.h_ctl, sizeof(Ctl) * (size_t)K, hipMemcpyHostToDevice, bc.stream)); // every slot idle
@@ -1511,7 +1533,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   for (;;) {
     for (int d = 0; d < depth; d++) {
       launch_select_queue(bc.d_ctl, q, bc.stream, Kact);
-      launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact);
+      launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact, 1);
     }
     HIPCHECK(hipMemcpyAsync(bc.h_cnt + 2, bc.d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, bc.stream));
     const bool drained_before = next_seen >= njobs; // as of the previous poll: no slot can pull a job any more
@@ -2098,6 +2120,7 @@ void tuning(int tr, int hot, int nt) {
   }
 }
 
+void set_dual_chain(int len) { g_dchain = (len <= 0) ? 0 : std::min(DCH_MAX, len); } // <= 0: by batch width / size
 void set_chain(int len) { g_chain = (len <= 0) ? 0 : std::min(KCH, len); } // 0: by tableau size
 void set_persist(int mode) {
   g_persist_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode); // 2: no size cap

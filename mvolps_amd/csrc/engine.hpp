@@ -41,6 +41,7 @@ void tuning(int tr, int hot, int nt);
 void set_stall_limit(int limit);
 void set_persist(int mode);
 void set_chain(int len);
+void set_dual_chain(int len);
 void set_refresh(int check_every, double tol);
 double row_residual(const mvx_prob *P);
 void persist_stats(long long *launches, long long *aborts);

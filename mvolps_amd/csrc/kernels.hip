@@ -420,11 +420,222 @@ __device__ __forceinline__ void dev_finish(Ctl *c, int code, int phase, int roun
   }
 }
 
+struct ChainStep {
+  int p, q, lf;
+  double piv, xq, s0; // s0 = srow_l[0]
+};
+
+// entry (i, j) with value v before step l -> after it; ci = column q_l entry of row i, sj = scaled pivot row entry of
+// column j (both as of step l)
+__device__ __forceinline__ double chain_apply(const ChainStep &st, int i, int j, double v, double ci, double sj) {
+  if (i == st.p) return (j == st.q) ? xdiv(1.0, st.piv) : ((j == 0) ? st.xq - sj : -sj);
+  if (j == st.q) return xdiv(ci, st.piv);
+  return fma(-ci, sj, v);
+}
+
+__device__ __forceinline__ const double *uniform_ptr(const double *p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (const double *)(((unsigned long long)hi << 32) | lo);
+}
+struct ChainView { // steps 0..k-1 as every lane needs them (one copy per block, in LDS)
+  ChainStep st[KCH];
+  double elb[KCH], eub[KCH], llb[KCH], lub[KCH];
+  const double *cq[KCH], *sr[KCH]; // pivot column / scaled pivot row of each step
+};
+// all threads of the block call; ends with a barrier
+__device__ __forceinline__ void chain_load(const Ctl *c, int k, ChainView &v) {
+  const int l = TIDX;
+  if (l < k) {
+    v.st[l] = ChainStep{c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l]};
+    v.elb[l] = c->ch_elb[l];
+    v.eub[l] = c->ch_eub[l];
+    v.llb[l] = c->ch_llb[l];
+    v.lub[l] = c->ch_lub[l];
+    v.cq[l] = (l == 0) ? c->colqx[c->curB] : c->colqk[l];
+    v.sr[l] = (l == 0) ? c->srow : c->srowk[l];
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ chained dual steps
+// The dual simplex counterpart of the chained primal path (see "chained primal path" below for the idea): after
+// select_step has prepared a dual pivot (step 0), the following dual pivots of the same solve are chosen by the same
+// workgroup from slices of the tableau as it stands -- column 0, the leaving row, the objective row, the entering
+// column -- carried through the earlier steps of the chain with chain_apply, and k_update then applies the whole chain
+// in one pass.  This is what every warm-started B&B child runs (bs.cpp:279,287): with 64-128 node LPs per launch the
+// pass over their tableaux is the cost of a step, and a chain divides it.  A chain ends (the next k_select carries on
+// from the updated tableau) on: pivot limit, stall limit, no infeasible row left, no entering column.  Bland's rule, a
+// dual phase that has just begun (weights restart) and the other phases never chain.
+__device__ int dual_chain(const KC &k, Ctl *c, Cand *lds, int kmax) {
+  __shared__ ChainView v;
+  __shared__ double s_val[2];
+  const int m = k.m, n = k.n, bs = (int)blockDim.x;
+  const size_t ld = (size_t)k.ld;
+  const double *const T = k.T;
+  const int budget = c->budget, stall_limit = c->stall_limit;
+  if (TIDX == 0) {
+    const int p0 = c->p, q0 = c->q;
+    v.st[0] = ChainStep{p0, q0, c->leave_flag, c->piv, c->xq, k.srow[0]};
+    v.elb[0] = k.nlb[q0];
+    v.eub[0] = k.nub[q0];
+    v.llb[0] = k.blb[p0];
+    v.lub[0] = k.bub[p0];
+    v.cq[0] = k.colq;
+    v.sr[0] = k.srow;
+    for (int l = 1; l < kmax; l++) {
+      v.cq[l] = c->colqk[l];
+      v.sr[l] = c->srowk[l];
+    }
+  }
+  __syncthreads();
+  int stall = c->stall; // select_step has just set it for step 0
+  int nch = 1;
+  for (int kk = 1; kk < kmax; kk++) {
+    if ((budget >= 0 && budget < kk + 1) || stall >= stall_limit) break;
+    // ---- leaving row: basic values and bounds as of step kk (dev_infeas_row on carried values)
+    Cand rbest{0.0, 0.0, 0, 0};
+    const double tolb = k.tol_bnd;
+    for (int i = 1 + TIDX; i <= m; i += bs) {
+      double beta = T[(size_t)i * ld];
+      double lb = k.blb[i], ub = k.bub[i];
+      for (int l = 0; l < kk; l++) {
+        beta = chain_apply(v.st[l], i, 0, beta, v.cq[l][i], v.st[l].s0);
+        if (v.st[l].p == i) {
+          lb = v.elb[l];
+          ub = v.eub[l];
+        }
+      }
+      double viol = 0.0;
+      int up = 0;
+      if (lb > -INFINITY && beta < lb - tolb * (1.0 + fabs(lb))) viol = lb - beta;
+      if (ub < INFINITY && beta > ub + tolb * (1.0 + fabs(ub))) {
+        viol = beta - ub;
+        up = 1;
+      }
+      if (viol > 0.0) {
+        Cand x{xdiv(viol * viol, k.dw[i]), 0.0, i, up};
+        if (cand_better<0>(x, rbest)) rbest = x;
+      }
+    }
+    rbest = block_best<0>(rbest, lds);
+    if (rbest.idx == 0) break; // primal feasible: the next k_select changes phase
+    const int p = rbest.idx, p_up = rbest.aux;
+    const double wp = k.dw[p]; // every lane reads it before its owner rewrites it below
+    // ---- row p and the objective row as of step kk: dual ratio test (dev_dual_ratio on carried values)
+    double *const sk = c->srowk[kk];
+    Cand best{0.0, 0.0, 0, 0};
+    const double tp = k.tol_piv, sgn = k.sgn;
+    const bool need_inc = !p_up;
+    for (int j = TIDX; j <= n; j += bs) {
+      double a = T[(size_t)p * ld + j];
+      double d0 = T[j];
+      int f = (j >= 1) ? k.nflag[j] : MVX_NS;
+      for (int l = 0; l < kk; l++) {
+        const double sj = v.sr[l][j];
+        a = chain_apply(v.st[l], p, j, a, v.cq[l][p], sj);
+        d0 = chain_apply(v.st[l], 0, j, d0, v.cq[l][0], sj);
+        if (v.st[l].q == j) f = v.st[l].lf;
+      }
+      sk[j] = a; // row p as of step kk; scaled in place once the pivot element is known
+      if (j == 0 || f == MVX_NS) continue;
+      const double aa = need_inc ? a : -a;
+      const double d = sgn * d0;
+      double r;
+      if (aa > tp && (f == MVX_NL || f == MVX_NF)) {
+        r = (f == MVX_NF) ? fabs(d) : (d < 0.0 ? -d : 0.0);
+      } else if (aa < -tp && (f == MVX_NU || f == MVX_NF)) {
+        r = (f == MVX_NF) ? fabs(d) : (d > 0.0 ? d : 0.0);
+      } else
+        continue;
+      const double mag = fabs(a);
+      r = xdiv(r, mag);
+      Cand x{r, mag, j, 0};
+      if (cand_better<1>(x, best)) best = x;
+    }
+    best = block_best<1>(best, lds);
+    if (best.idx == 0) break; // no entering column: the generic step reports it
+    const int q = best.idx;
+    // the entering variable and the leaving row as the earlier steps left them
+    double lbq = k.nlb[q], ubq = k.nub[q];
+    int fq = k.nflag[q];
+    double plb = k.blb[p], pub = k.bub[p];
+    for (int l = 0; l < kk; l++) {
+      if (v.st[l].q == q) {
+        lbq = v.llb[l];
+        ubq = v.lub[l];
+        fq = v.st[l].lf;
+      }
+      if (v.st[l].p == p) {
+        plb = v.elb[l];
+        pub = v.eub[l];
+      }
+    }
+    const double apq = sk[q]; // written above by the lane that owns column q (barriers inside block_best)
+    __syncthreads(); // ... and rescaled in place further down: every lane has its copy before any lane gets there
+    const double bound = p_up ? pub : plb;
+    const int lf = dev_leave_flag(plb, pub, p_up);
+    // ---- column q as of step kk + dual devex weights (select_step's pass over the rows)
+    double *const ck = c->colqk[kk];
+    for (int i = TIDX; i <= m; i += bs) {
+      double a = T[(size_t)i * ld + q];
+      for (int l = 0; l < kk; l++) a = chain_apply(v.st[l], i, q, a, v.cq[l][i], v.sr[l][q]);
+      ck[i] = a;
+      if (i == 0) continue;
+      if (i == p) {
+        const double cc = xdiv(wp, apq * apq);
+        k.dw[i] = cc > 1.0 ? cc : 1.0;
+      } else {
+        const double r = xdiv(a, apq);
+        const double cc = r * r * wp;
+        double wi = k.dw[i];
+        if (cc > wi) wi = cc;
+        k.dw[i] = wi;
+      }
+    }
+    // ---- scaled pivot row (dev_prepare_pivot)
+    for (int j = TIDX; j <= n; j += bs) {
+      const double a = sk[j];
+      const double sj = (j == 0) ? xdiv(a - bound, apq) : xdiv(a, apq);
+      sk[j] = sj;
+      if (j == 0) s_val[0] = sj;
+    }
+    stall = (best.k1 <= DEGEN_TOL) ? stall + 1 : 0;
+    __syncthreads();
+    if (TIDX == 0) {
+      v.st[kk] = ChainStep{p, q, lf, apq, dev_nb_value(fq, lbq, ubq), s_val[0]};
+      v.elb[kk] = lbq;
+      v.eub[kk] = ubq;
+      v.llb[kk] = plb;
+      v.lub[kk] = pub;
+      c->ch_p[kk] = p;
+      c->ch_q[kk] = q;
+      c->ch_lf[kk] = lf;
+      c->ch_piv[kk] = apq;
+      c->ch_xq[kk] = v.st[kk].xq;
+      c->ch_s0[kk] = s_val[0];
+    }
+    __syncthreads();
+    nch = kk + 1;
+  }
+  if (TIDX == 0) {
+    c->ch_p[0] = v.st[0].p;
+    c->ch_q[0] = v.st[0].q;
+    c->ch_lf[0] = v.st[0].lf;
+    c->ch_piv[0] = v.st[0].piv;
+    c->ch_xq[0] = v.st[0].xq;
+    c->ch_s0[0] = v.st[0].s0;
+    c->stall = stall;
+  }
+  return nch;
+}
+
 // ---------------------------------------------------------------------------- k_select
 // Device-side restatement of orc_simplex's round loop + one pricing / ratio-test step.
 __device__ void select_step(Ctl *c, Cand *lds) {
   const KC k = load_kc(c); // every pointer / constant the step needs, fetched in one burst
   if (c->done != D_RUN) return;
+  if (TIDX == 0) c->nch = 1; // whatever step this call prepares is a single one unless a dual chain says otherwise below
   const int ne = c->n_edits;
   if (ne) { // first step of a solve: the bound edits made since the last one (one lane each)
     if (TIDX < ne) {
@@ -436,6 +647,7 @@ __device__ void select_step(Ctl *c, Cand *lds) {
     if (TIDX == 0) c->n_edits = 0;
   }
   int phase = c->phase, rounds = c->rounds;
+  int nch = 1; // pivots the coming k_update applies (dual chains)
   int p = 0, p_up = 0, q = 0, sdir = 0, kind = 0; // kind 1 primal, 2 dual
   bool fresh_dual = false; // the dual phase starts with this step: devex weights restart from one
   bool fresh_primal = false; // primal phase 2 starts with this step: likewise
@@ -564,10 +776,15 @@ __device__ void select_step(Ctl *c, Cand *lds) {
       if (k.bland) c->n_bland++;
       c->stall = (dr.k1 <= DEGEN_TOL) ? c->stall + 1 : 0;
     }
+    if (c->dchain_max > 1 && !fresh_dual && !k.bland && phase == PH_DUAL) {
+      __syncthreads(); // step 0 is complete: srow, colq, weights, the control block's pivot description
+      nch = dual_chain(k, c, lds, c->dchain_max);
+    }
   }
   if (TIDX == 0) {
     c->phase = phase;
     c->rounds = rounds;
+    c->nch = nch;
   }
 }
 
@@ -629,6 +846,11 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
       const SlotScratch sp = q.scratch[blockIdx.z];
       c->colq = sp.colq; c->srow = sp.srow; c->olb = sp.olb; c->oub = sp.oub; c->dw = sp.dw; c->dwx[0] = c->dwx[1] = sp.dw;
       c->pw[0] = c->pw[1] = sp.pw;
+      for (int l = 1; l < DCH_MAX; l++) { // dual chains: this slot's per-step buffers
+        unsigned char *b = reinterpret_cast<unsigned char *>(sp.chain) + (size_t)(l - 1) * sp.chain_stride;
+        c->colqk[l] = reinterpret_cast<double *>(b);
+        c->srowk[l] = reinterpret_cast<double *>(b + sp.chain_col);
+      }
       c->job = j;
     }
     __syncthreads();
@@ -861,10 +1083,93 @@ __device__ __forceinline__ void st2(double2 *p, double2 v) {
 //   T[i][q] = colq[i] / piv                      (i != p)
 //   T[p][j] = -srow[j], T[p][q] = 1/piv, T[p][0] = xq - srow[0]
 // Block = 256 lanes x 2 columns (16 B per lane, 4 KB per row segment), TR rows deep.
+// k_update for a chain of dual pivots (dual_chain): the tile is loaded once, the steps are applied in registers in
+// order, stored once; the basis swaps of the chain in order.  Rows 0..m (the objective row is an ordinary row here).
 template <int TR, int NT>
-__global__ __launch_bounds__(256) void k_update(Ctl *c) {
+__device__ __forceinline__ void update_chain(Ctl *c, int nch) {
+  __shared__ ChainStep s_st[KCH];
+  __shared__ const double *s_cq[KCH], *s_sr[KCH];
+  const int m = c->m, n = c->n;
+  const size_t ld = (size_t)c->ld;
+  if (TIDX < nch) {
+    const int l = TIDX;
+    s_st[l] = ChainStep{c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l]};
+    s_cq[l] = (l == 0) ? c->colq : c->colqk[l];
+    s_sr[l] = (l == 0) ? c->srow : c->srowk[l];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && TIDX == 0) {
+    for (int l = 0; l < nch; l++) {
+      const int p = s_st[l].p, q = s_st[l].q;
+      const int kv = c->bvar[p];
+      const double klb = c->blb[p], kub = c->bub[p];
+      c->bvar[p] = c->nvar[q];
+      c->blb[p] = c->nlb[q];
+      c->bub[p] = c->nub[q];
+      c->nvar[q] = kv;
+      c->nlb[q] = klb;
+      c->nub[q] = kub;
+      c->nflag[q] = s_st[l].lf;
+    }
+    c->it_cnt += nch;
+    c->n_bulk++;
+    if (c->budget > 0) c->budget -= nch;
+  }
+  const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
+  const int i0 = (int)blockIdx.y * TR;
+  if (j0 > n || i0 > m) return;
+  double *base = c->T + (size_t)i0 * ld + j0;
+  double2 v[TR];
+#pragma unroll
+  for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
+  for (int l = 0; l < nch; l++) {
+    const ChainStep st = s_st[l];
+    const double2 s = *reinterpret_cast<const double2 *>(uniform_ptr(s_sr[l]) + j0);
+    const double *cql = uniform_ptr(s_cq[l]) + i0;
+    double ci[TR];
+#pragma unroll
+    for (int r = 0; r < TR; r++) ci[r] = cql[r];
+    const bool q0 = (j0 == st.q), q1 = (j0 + 1 == st.q);
+#pragma unroll
+    for (int r = 0; r < TR; r++) {
+      v[r].x = fma(-ci[r], s.x, v[r].x);
+      v[r].y = fma(-ci[r], s.y, v[r].y);
+    }
+    if (q0 || q1) {
+#pragma unroll
+      for (int r = 0; r < TR; r++) {
+        const double qv = xdiv(ci[r], st.piv);
+        if (q0) v[r].x = qv;
+        if (q1) v[r].y = qv;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (st.p >= i0 && st.p < i0 + TR) {
+#pragma unroll
+      for (int r = 0; r < TR; r++) {
+        if (i0 + r == st.p) {
+          v[r].x = q0 ? xdiv(1.0, st.piv) : -s.x;
+          v[r].y = q1 ? xdiv(1.0, st.piv) : -s.y;
+          if (j0 == 0) v[r].x = st.xq - s.x;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
+}
+
+template <int TR, int NT>
+__global__ __launch_bounds__(256) void k_update(Ctl *c, int chained) {
   c += blockIdx.z;
   if (c->done != D_RUN || c->step != ST_PIVOT) return;
+  if (chained) {
+    const int nch = c->nch;
+    if (nch > 1) {
+      update_chain<TR, NT>(c, nch);
+      return;
+    }
+  }
   const int m = c->m, n = c->n, p = c->p, q = c->q;
   const size_t ld = (size_t)c->ld;
   const double piv = c->piv;
@@ -1462,19 +1767,6 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 // applies all the steps to every entry in registers.  Same pivots, same bits as one launch per pivot -- the traffic per
 // pivot is what changes.  A chain ends early (the remaining work is then the ordinary path's) on: pivot limit, stall
 // limit, no entering column, a bound flip, an unbounded ray.
-struct ChainStep {
-  int p, q, lf;
-  double piv, xq, s0; // s0 = srow_l[0]
-};
-
-// entry (i, j) with value v before step l -> after it; ci = column q_l entry of row i, sj = scaled pivot row entry of
-// column j (both as of step l)
-__device__ __forceinline__ double chain_apply(const ChainStep &st, int i, int j, double v, double ci, double sj) {
-  if (i == st.p) return (j == st.q) ? xdiv(1.0, st.piv) : ((j == 0) ? st.xq - sj : -sj);
-  if (j == st.q) return xdiv(ci, st.piv);
-  return fma(-ci, sj, v);
-}
-
 // Step k >= 1 of a chain takes two small multi-workgroup launches, the counterparts of what k_fb's column export and
 // k_fa do for step 0:
 //   k_fcc (one lane per row): entering column q_k = reduction of the pricing partials; column q_k and the basic values as
@@ -1486,31 +1778,6 @@ __device__ __forceinline__ double chain_apply(const ChainStep &st, int i, int j,
 // Every block of a kernel reaches the same verdict on whether the chain goes on (the reduction keys are a total order),
 // and only the lead lane writes it down -- for the NEXT kernel; a block that starts late and finds the chain already
 // closed returns, as it would have decided itself.
-__device__ __forceinline__ const double *uniform_ptr(const double *p) {
-  const unsigned long long a = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return (const double *)(((unsigned long long)hi << 32) | lo);
-}
-struct ChainView { // steps 0..k-1 as every lane needs them (one copy per block, in LDS)
-  ChainStep st[KCH];
-  double elb[KCH], eub[KCH], llb[KCH], lub[KCH];
-  const double *cq[KCH], *sr[KCH]; // pivot column / scaled pivot row of each step
-};
-// all threads of the block call; ends with a barrier
-__device__ __forceinline__ void chain_load(const Ctl *c, int k, ChainView &v) {
-  const int l = TIDX;
-  if (l < k) {
-    v.st[l] = ChainStep{c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l]};
-    v.elb[l] = c->ch_elb[l];
-    v.eub[l] = c->ch_eub[l];
-    v.llb[l] = c->ch_llb[l];
-    v.lub[l] = c->ch_lub[l];
-    v.cq[l] = (l == 0) ? c->colqx[c->curB] : c->colqk[l];
-    v.sr[l] = (l == 0) ? c->srow : c->srowk[l];
-  }
-  __syncthreads();
-}
-
 __global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
   __shared__ Cand lds[17];
   __shared__ ChainView v;
@@ -2687,18 +2954,18 @@ void launch_select(Ctl *d_ctl, hipStream_t s, int slots) {
 void launch_select_queue(Ctl *d_ctl, const BatchQueue &q, hipStream_t s, int slots) {
   hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl, q);
 }
-void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
+void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots, int chained) {
   const int pairs = (n + 2) / 2;
   const long tiles = (pairs + 255) / 256;
   // 16-row tiles once the launch still has >= 2048 workgroups, else 8, else 4 (latency-bound sizes)
   const int tr = ((long)((m + 16) / 16) * tiles * slots >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * slots >= 2048) ? 8 : 4;
   dim3 grid((unsigned)tiles, (m + tr) / tr, slots);
   const int nt = (tr == 16) ? pick_nt(m, n) : 0;
-  if (nt == 1) hipLaunchKernelGGL((k_update<16, 1>), grid, dim3(256), 0, s, d_ctl);
-  else if (nt == 2) hipLaunchKernelGGL((k_update<16, 2>), grid, dim3(256), 0, s, d_ctl);
-  else if (tr == 16) hipLaunchKernelGGL((k_update<16, 0>), grid, dim3(256), 0, s, d_ctl);
-  else if (tr == 8) hipLaunchKernelGGL((k_update<8, 0>), grid, dim3(256), 0, s, d_ctl);
-  else hipLaunchKernelGGL((k_update<4, 0>), grid, dim3(256), 0, s, d_ctl);
+  if (nt == 1) hipLaunchKernelGGL((k_update<16, 1>), grid, dim3(256), 0, s, d_ctl, chained);
+  else if (nt == 2) hipLaunchKernelGGL((k_update<16, 2>), grid, dim3(256), 0, s, d_ctl, chained);
+  else if (tr == 16) hipLaunchKernelGGL((k_update<16, 0>), grid, dim3(256), 0, s, d_ctl, chained);
+  else if (tr == 8) hipLaunchKernelGGL((k_update<8, 0>), grid, dim3(256), 0, s, d_ctl, chained);
+  else hipLaunchKernelGGL((k_update<4, 0>), grid, dim3(256), 0, s, d_ctl, chained);
 }
 void launch_p1_head(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_head, dim3(1), dim3(1024), 0, s, d_ctl); }
 void launch_p1_select(Ctl *d_ctl, hipStream_t s) { hipLaunchKernelGGL(k_p1_select, dim3(1), dim3(1024), 0, s, d_ctl); }

@@ -27,6 +27,7 @@ constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound pe
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
 constexpr size_t WT_MIN_BYTES = (size_t)96 << 20, WT_MAX_BYTES = (size_t)272 << 20; // write-through stores in this band (pick_nt)
 constexpr int KCH = 16;          // most pivots one bulk launch of the chained primal path applies (k_fc / k_fbc)
+constexpr int DCH_MAX = 8;       // most dual pivots one k_update applies (dual_chain)
 constexpr int DA_THREADS = 1024; // k_dboot / k_da workgroup size: the O(m) leaving-row pass is redundant per block
 constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
@@ -110,6 +111,7 @@ struct Ctl {
   // and ONE bulk launch applies the whole chain (each entry read and written once for up to KCH pivots).  Step 0 of a
   // chain is the step k_fa left in the fields above; ch_*[l] describes step l >= 1 (index 0 is filled for uniform loops).
   int chain_max, nch; // chain length allowed by the host (1 = off) / prepared for the coming bulk launch
+  int dchain_max;     // the same for the dual steps of the generic path (dual_chain in k_select)
   int n_bulk;         // bulk launches that stepped so far in this solve (one per pivot or flip; one per chain)
   int ch_alive, ch_nrpc; // the chain may still grow / ratio-test partials k_fcc left
   int ch_p[KCH], ch_q[KCH], ch_pup[KCH], ch_lf[KCH], ch_stall[KCH], ch_sdir[KCH], ch_fq[KCH];
@@ -125,6 +127,8 @@ struct Ctl {
 // next job in the very launch that finds it idle, instead of idling until the host's next synchronisation point.
 struct SlotScratch { // per-slot scratch the pulled control block is pointed at
   double *colq, *srow, *olb, *oub, *dw, *pw;
+  double *chain; // DCH_MAX - 1 x (pivot column [m_cap+1 rounded], scaled pivot row [ld]) for dual chains
+  size_t chain_col, chain_stride; // bytes: offset of the row part inside one step's pair, size of a pair
 };
 struct BatchQueue {
   const Ctl *jobs;
