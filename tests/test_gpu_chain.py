@@ -103,3 +103,87 @@ def test_chain_length_by_size_is_the_default(gpu, orc):
         P.load_dense(A, b, c)
         assert P.simplex(it_lim=150) == capi.EITLIM
     assert_same_state(g, o, "1024x4096, 150 pivots")
+
+
+# ---------------------------------------------------------------- chained dual steps (dual_chain in k_select)
+@pytest.fixture
+def dual_chained(gpu):
+    yield gpu
+    gpu.set_dual_chain(0)
+
+
+@pytest.mark.parametrize("chain", [2, 5, 8])
+def test_dual_chains_in_branch_and_bound(dual_chained, orc, chain):
+    """Every warm-started child runs the dual simplex: trees, events and pivot counts equal the oracle's with the dual
+    pivots chained 2, 5 and 8 to a pass (window mode and node at a time, plain and with GMI cut rows appended)."""
+    from mvolps_amd import bnb
+    from oracle import oracle
+
+    from .test_gpu_bnb import same_result
+
+    dual_chained.set_dual_chain(chain)
+    for case, kw in (((10, 20, 4, 3), dict(quirks=0)), ((16, 32, 5, 2), dict(quirks=1, max_nodes=600)),
+                     ((10, 20, 4, 3), dict(quirks=0, cut_strat=1)), ((16, 32, 5, 2), dict(quirks=1, cut_strat=1, max_nodes=300))):
+        A, b, c, U = synth.dense_ilp(*case)
+        ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), **kw)
+        for window in (1, 64):
+            got = bnb.branch_and_bound(lpgen.load_ilp(dual_chained, A, b, c, U), window=window, **kw)
+            same_result(got, ref)
+
+
+@pytest.mark.parametrize("chain", [3, 8])
+def test_dual_chains_on_512x1024_children(dual_chained, orc, chain):
+    """The calibrated config-5 instance: root + both children of its first eight fractional columns, each child
+    hundreds of dual pivots (n + 1 = 1025 columns on 1024 lanes: the lane that owns the entering column can be one
+    that has no row to work on, which is where an unsynchronised read of the pivot element once raced with its
+    rescaling), solved twice over (recycled slabs)."""
+    import json
+    import os
+
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5.json")))
+    A, b, c, U = synth.dense_ilp(fx["m"], fx["n"], fx["seed"], fx["U"], fx["cap"])
+    dual_chained.set_dual_chain(chain)
+    g, o = synth.load_ilp(dual_chained, A, b, c, U), synth.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    assert_same_state(g, o, "root")
+    x = o.col_prim()
+    frac = [j + 1 for j in range(len(x)) if abs(x[j] - round(x[j])) > 1e-9][:8]
+    ref = {}
+    for j in frac:
+        for up in (0, 1):
+            k = o.copy()
+            orc.set_col_bnds(k.h, j, capi.DB, *((float(np.ceil(x[j - 1])), 1.0) if up else (0.0, float(np.floor(x[j - 1])))))
+            k.simplex()
+            ref[(j, up)] = k
+    for rep in range(2):
+        for j in frac:
+            for up in (0, 1):
+                k = g.copy()
+                dual_chained.set_col_bnds(k.h, j, capi.DB, *((float(np.ceil(x[j - 1])), 1.0) if up else (0.0, float(np.floor(x[j - 1])))))
+                k.simplex()
+                assert_same_state(k, ref[(j, up)], "child %d/%d rep %d chain %d" % (j, up, rep, chain))
+
+
+@pytest.mark.parametrize("chain", [3, 8])
+def test_dual_chains_on_general_lps_with_warm_starts(dual_chained, orc, chain):
+    dual_chained.set_dual_chain(chain)
+    rng = np.random.default_rng(11)
+    seen = set()
+    for trial in range(80):
+        A, row_b, col_b, c, direction = lpgen.random_general_lp(rng, mmax=60, nmax=90)
+        g, o = dual_chained.create(), orc.create()
+        for P in (g, o):
+            P.load_general(A, row_b, col_b, c, direction=direction)
+            P.rc = P.simplex()
+        assert g.rc == o.rc
+        assert_same_state(g, o, "general %d" % trial)
+        j = int(rng.integers(1, A.shape[1] + 1))
+        v = float(rng.integers(-2, 4))
+        for P in (g, o):
+            P.api.set_col_bnds(P.h, j, capi.DB, v, v + 1.0)
+            P.rc = P.simplex()
+        assert g.rc == o.rc
+        assert_same_state(g, o, "general %d warm" % trial)
+        seen.add(g.status)
+    assert len(seen) >= 2
