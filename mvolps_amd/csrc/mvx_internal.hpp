@@ -27,7 +27,7 @@ constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound pe
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
 constexpr size_t WT_MIN_BYTES = (size_t)96 << 20, WT_MAX_BYTES = (size_t)272 << 20; // write-through stores in this band (pick_nt)
 constexpr int KCH = 16;          // most pivots one bulk launch of the chained primal path applies (k_fc / k_fbc)
-constexpr int DCH_MAX = 8;       // most dual pivots one k_update applies (dual_chain)
+constexpr int DCH_MAX = 8;  // most dual pivots one k_update applies (dual_chain)
 constexpr int DA_THREADS = 1024; // k_dboot / k_da workgroup size: the O(m) leaving-row pass is redundant per block
 constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
 constexpr int ROW_SPARE = 32;     // rows behind row m that always exist: k_fb streams whole row tiles
