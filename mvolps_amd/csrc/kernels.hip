@@ -1117,18 +1117,24 @@ __device__ __forceinline__ void update_chain(Ctl *c, int nch) {
   }
   const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
   const int i0 = (int)blockIdx.y * TR;
-  if (j0 > n || i0 > m) return;
+  if (i0 > m || 2 * (int)blockIdx.x * 256 > n) return; // block-uniform: the whole block is outside this slot's tableau
+  // the pivot-column entries of the tile for every step, one load per lane (DCH_MAX * TR <= 256)
+  __shared__ double s_ci[DCH_MAX][TR];
+  if (TIDX < nch * TR) s_ci[TIDX / TR][TIDX % TR] = s_cq[TIDX / TR][i0 + TIDX % TR];
+  __syncthreads();
+  if (j0 > n) return;
   double *base = c->T + (size_t)i0 * ld + j0;
   double2 v[TR];
 #pragma unroll
   for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
+  double2 s_n = *reinterpret_cast<const double2 *>(uniform_ptr(s_sr[0]) + j0);
   for (int l = 0; l < nch; l++) {
     const ChainStep st = s_st[l];
-    const double2 s = *reinterpret_cast<const double2 *>(uniform_ptr(s_sr[l]) + j0);
-    const double *cql = uniform_ptr(s_cq[l]) + i0;
+    const double2 s = s_n;
+    if (l + 1 < nch) s_n = *reinterpret_cast<const double2 *>(uniform_ptr(s_sr[l + 1]) + j0);
     double ci[TR];
 #pragma unroll
-    for (int r = 0; r < TR; r++) ci[r] = cql[r];
+    for (int r = 0; r < TR; r++) ci[r] = s_ci[l][r];
     const bool q0 = (j0 == st.q), q1 = (j0 + 1 == st.q);
 #pragma unroll
     for (int r = 0; r < TR; r++) {
@@ -1960,32 +1966,24 @@ __global__ __launch_bounds__(256) void k_fbc(Ctl *c) {
   const Cand *ppn = c->pp[nxt];
   Cand ncv = ((TIDX & 63) < npb) ? ppn[TIDX & 63] : Cand{0.0, 0.0, 0, 0};
   chain_load(c, nch, cv);
+  __shared__ double s_ci[KCH][TR];
+  if (TIDX < nch * TR) s_ci[TIDX / TR][TIDX % TR] = cv.cq[TIDX / TR][i0 + TIDX % TR];
+  __syncthreads();
   if (active) {
     double *base = c->T + (size_t)i0 * ld + j0;
     double2 v[TR];
 #pragma unroll
     for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
-    // the step's pointers come out of LDS: made wave-uniform by hand so that the pivot-column entries of the tile are
-    // fetched by scalar loads, as k_fb's are; step l+1's operands are requested while step l is applied
+    // the pivot-column entries of the tile for every step sit in LDS (one load per lane up front instead of TR vector
+    // loads per lane and step); step l+1's pivot-row pair is requested while step l is applied
     double2 s_n = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[0]) + j0);
-    double ci_n[TR];
-    {
-      const double *cql = uniform_ptr(cv.cq[0]) + i0;
-#pragma unroll
-      for (int r = 0; r < TR; r++) ci_n[r] = cql[r];
-    }
     for (int l = 0; l < nch; l++) {
       const ChainStep st = cv.st[l];
       const double2 s = s_n;
       double ci[TR];
 #pragma unroll
-      for (int r = 0; r < TR; r++) ci[r] = ci_n[r];
-      if (l + 1 < nch) {
-        s_n = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[l + 1]) + j0);
-        const double *cql = uniform_ptr(cv.cq[l + 1]) + i0;
-#pragma unroll
-        for (int r = 0; r < TR; r++) ci_n[r] = cql[r];
-      }
+      for (int r = 0; r < TR; r++) ci[r] = s_ci[l][r];
+      if (l + 1 < nch) s_n = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[l + 1]) + j0);
       const bool q0 = (j0 == st.q), q1 = (j0 + 1 == st.q);
 #pragma unroll
       for (int r = 0; r < TR; r++) {
