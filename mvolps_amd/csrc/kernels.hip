@@ -443,20 +443,42 @@ struct ChainView { // steps 0..k-1 as every lane needs them (one copy per block,
   double elb[KCH], eub[KCH], llb[KCH], lub[KCH];
   const double *cq[KCH], *sr[KCH]; // pivot column / scaled pivot row of each step
 };
-// all threads of the block call; ends with a barrier
-__device__ __forceinline__ void chain_load(const Ctl *c, int k, ChainView &v) {
+// One lane's share of the chain description: fetched from the control block together with everything else the kernel
+// reads there (the same dependent-load level), handed to LDS once the kernel knows it has work.
+struct ChainRec {
+  ChainStep st;
+  double elb, eub, llb, lub;
+  const double *cq, *sr;
+};
+__device__ __forceinline__ ChainRec chain_fetch(const Ctl *c, int k) {
+  ChainRec r{};
   const int l = TIDX;
   if (l < k) {
-    v.st[l] = ChainStep{c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l]};
-    v.elb[l] = c->ch_elb[l];
-    v.eub[l] = c->ch_eub[l];
-    v.llb[l] = c->ch_llb[l];
-    v.lub[l] = c->ch_lub[l];
-    v.cq[l] = (l == 0) ? c->colqx[c->curB] : c->colqk[l];
-    v.sr[l] = (l == 0) ? c->srow : c->srowk[l];
+    r.st = ChainStep{c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l]};
+    r.elb = c->ch_elb[l];
+    r.eub = c->ch_eub[l];
+    r.llb = c->ch_llb[l];
+    r.lub = c->ch_lub[l];
+    r.cq = (l == 0) ? c->colqx[c->curB] : c->colqk[l];
+    r.sr = (l == 0) ? c->srow : c->srowk[l];
+  }
+  return r;
+}
+// all threads of the block call; ends with a barrier
+__device__ __forceinline__ void chain_store(const ChainRec &r, int k, ChainView &v) {
+  const int l = TIDX;
+  if (l < k) {
+    v.st[l] = r.st;
+    v.elb[l] = r.elb;
+    v.eub[l] = r.eub;
+    v.llb[l] = r.llb;
+    v.lub[l] = r.lub;
+    v.cq[l] = r.cq;
+    v.sr[l] = r.sr;
   }
   __syncthreads();
 }
+__device__ __forceinline__ void chain_load(const Ctl *c, int k, ChainView &v) { chain_store(chain_fetch(c, k), k, v); }
 
 // ------------------------------------------------------------------ chained dual steps
 // The dual simplex counterpart of the chained primal path (see "chained primal path" below for the idea): after
@@ -1787,6 +1809,7 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 __global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
   __shared__ Cand lds[17];
   __shared__ ChainView v;
+  const ChainRec rec = chain_fetch(c, k); // same load level as the fields below
   if (c->done != D_RUN || c->fstate != F_RUN || !c->ch_alive) return;
   const bool lead = (blockIdx.x == 0 && TIDX == 0);
   const int cur = c->curB, nxt = cur ^ 1;
@@ -1807,7 +1830,7 @@ __global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
     return;
   }
   const int q = pc.idx, sdir = pc.aux;
-  chain_load(c, k, v);
+  chain_store(rec, k, v);
   double *const ck = c->colqk[k];
   const int i = 1 + (int)blockIdx.x * 256 + TIDX;
   Cand rb{0.0, 0.0, 0, 0};
@@ -1857,6 +1880,7 @@ __global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
 __global__ __launch_bounds__(256) void k_fcr(Ctl *c, int k) {
   __shared__ Cand lds[17];
   __shared__ ChainView v;
+  const ChainRec rec = chain_fetch(c, k); // same load level as the fields below
   if (c->done != D_RUN || c->fstate != F_RUN || !c->ch_alive) return;
   const bool lead = (blockIdx.x == 0 && TIDX == 0);
   const int cur = c->curB, nxt = cur ^ 1;
@@ -1883,7 +1907,7 @@ __global__ __launch_bounds__(256) void k_fcr(Ctl *c, int k) {
     return;
   }
   const int p = rc.idx, p_up = rc.aux;
-  chain_load(c, k, v);
+  chain_store(rec, k, v);
   double plb = c->blb[p], pub = c->bub[p];
   for (int l = 0; l < k; l++)
     if (v.st[l].p == p) {
