@@ -1831,6 +1831,9 @@ __global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
   }
   const int q = pc.idx, sdir = pc.aux;
   chain_store(rec, k, v);
+  __shared__ double s_sq[KCH]; // scaled pivot row entries of column q, steps 0..k-1: one load each instead of one per lane
+  if (TIDX < k) s_sq[TIDX] = v.sr[TIDX][q];
+  __syncthreads();
   double *const ck = c->colqk[k];
   const int i = 1 + (int)blockIdx.x * 256 + TIDX;
   Cand rb{0.0, 0.0, 0, 0};
@@ -1840,7 +1843,7 @@ __global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
     double lb = c->blb[i], ub = c->bub[i];
     for (int l = 0; l < k; l++) {
       const double ci = v.cq[l][i];
-      a = chain_apply(v.st[l], i, q, a, ci, v.sr[l][q]);
+      a = chain_apply(v.st[l], i, q, a, ci, s_sq[l]);
       beta = chain_apply(v.st[l], i, 0, beta, ci, v.st[l].s0);
       if (v.st[l].p == i) {
         lb = v.elb[l];
@@ -1908,6 +1911,9 @@ __global__ __launch_bounds__(256) void k_fcr(Ctl *c, int k) {
   }
   const int p = rc.idx, p_up = rc.aux;
   chain_store(rec, k, v);
+  __shared__ double s_cp[KCH]; // pivot column entries of row p, steps 0..k-1: one load each instead of one per lane
+  if (TIDX < k) s_cp[TIDX] = v.cq[TIDX][p];
+  __syncthreads();
   double plb = c->blb[p], pub = c->bub[p];
   for (int l = 0; l < k; l++)
     if (v.st[l].p == p) {
@@ -1924,7 +1930,7 @@ __global__ __launch_bounds__(256) void k_fcr(Ctl *c, int k) {
   double s0 = 0.0;
   if (j <= n) {
     double val = T[(size_t)p * ld + j];
-    for (int l = 0; l < k; l++) val = chain_apply(v.st[l], p, j, val, v.cq[l][p], v.sr[l][j]);
+    for (int l = 0; l < k; l++) val = chain_apply(v.st[l], p, j, val, s_cp[l], v.sr[l][j]);
     const double sj = (j == 0) ? xdiv(val - bound, piv) : xdiv(val, piv);
     sk[j] = sj;
     s0 = sj;
