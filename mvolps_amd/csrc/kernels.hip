@@ -1830,17 +1830,21 @@ __global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
     return;
   }
   const int q = pc.idx, sdir = pc.aux;
-  chain_store(rec, k, v);
-  __shared__ double s_sq[KCH]; // scaled pivot row entries of column q, steps 0..k-1: one load each instead of one per lane
-  if (TIDX < k) s_sq[TIDX] = v.sr[TIDX][q];
-  __syncthreads();
-  double *const ck = c->colqk[k];
+  // this lane's row of the tableau as it stands: requested before the barriers below, used after them
   const int i = 1 + (int)blockIdx.x * 256 + TIDX;
+  double a = 0.0, beta = 0.0, lb = 0.0, ub = 0.0;
+  if (i <= m) {
+    a = T[(size_t)i * ld + q];
+    beta = c->betac[cur][i];
+    lb = c->blb[i];
+    ub = c->bub[i];
+  }
+  __shared__ double s_sq[KCH]; // scaled pivot row entries of column q, steps 0..k-1: one load each instead of one per lane
+  if (TIDX < k) s_sq[TIDX] = rec.sr[q];
+  chain_store(rec, k, v); // (ends with the barrier that also publishes s_sq)
+  double *const ck = c->colqk[k];
   Cand rb{0.0, 0.0, 0, 0};
   if (i <= m) {
-    double a = T[(size_t)i * ld + q];
-    double beta = c->betac[cur][i];
-    double lb = c->blb[i], ub = c->bub[i];
     for (int l = 0; l < k; l++) {
       const double ci = v.cq[l][i];
       a = chain_apply(v.st[l], i, q, a, ci, s_sq[l]);
@@ -1910,31 +1914,33 @@ __global__ __launch_bounds__(256) void k_fcr(Ctl *c, int k) {
     return;
   }
   const int p = rc.idx, p_up = rc.aux;
-  chain_store(rec, k, v);
+  // what this lane needs of the tableau as it stands and of the leaving row's record: requested before the barrier
+  const int j = (int)blockIdx.x * 256 + TIDX;
+  const double val0 = (j <= n) ? T[(size_t)p * ld + j] : 0.0;
+  const double dold0 = (j <= n) ? T[j] : 0.0;
+  const double piv = c->colqk[k][p];
   __shared__ double s_cp[KCH]; // pivot column entries of row p, steps 0..k-1: one load each instead of one per lane
-  if (TIDX < k) s_cp[TIDX] = v.cq[TIDX][p];
-  __syncthreads();
+  if (TIDX < k) s_cp[TIDX] = rec.cq[p];
+  chain_store(rec, k, v); // (ends with the barrier that also publishes s_cp)
   double plb = c->blb[p], pub = c->bub[p];
   for (int l = 0; l < k; l++)
     if (v.st[l].p == p) {
       plb = v.elb[l];
       pub = v.eub[l];
     }
-  const double piv = c->colqk[k][p];
   const double bound = p_up ? pub : plb;
   const int lf = dev_leave_flag(plb, pub, p_up);
   double *const pw = c->pw[nxt];
   double *const sk = c->srowk[k];
-  const int j = (int)blockIdx.x * 256 + TIDX;
   Cand best{0.0, 0.0, 0, 0};
   double s0 = 0.0;
   if (j <= n) {
-    double val = T[(size_t)p * ld + j];
+    double val = val0;
     for (int l = 0; l < k; l++) val = chain_apply(v.st[l], p, j, val, s_cp[l], v.sr[l][j]);
     const double sj = (j == 0) ? xdiv(val - bound, piv) : xdiv(val, piv);
     sk[j] = sj;
     s0 = sj;
-    const double dold = T[j];
+    const double dold = dold0;
     const double dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dold);
     T[j] = dnew;
     if (j >= 1) {
