@@ -979,7 +979,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
         if (depth > 0) {
           launch_fboot(sc.d_ctl, n, sc.stream);
           launch_fb(sc.d_ctl, m_grid, n, sc.stream, 1);
-          // chained path: k_fc extends the step k_fa prepared into a chain of up to `kc` pivots that ONE bulk launch
+          // chained path: k_fcc / k_fcr extend the step k_fa prepared into a chain of up to `kc` pivots that ONE bulk launch
           // applies, so `depth` pivots take depth / kc passes over the tableau when every chain fills (a chain that
           // ends early leaves pivots for the next batch)
           int kc = (J.chain > 1 && chain_supported(m_grid, n)) ? J.chain : 1;

@@ -1786,8 +1786,8 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 }
 
 // ================================================================= chained primal path
-// One pass over the tableau for up to KCH pivots.  After k_fa has prepared step 0 of a chain, k_fc (ONE workgroup)
-// chooses the following steps without the bulk update having run: everything the selection of step k reads -- the
+// One pass over the tableau for up to KCH pivots.  After k_fa has prepared step 0 of a chain, k_fcc / k_fcr (two small
+// launches per step) choose the following steps without the bulk update having run: everything the selection of step k reads -- the
 // entering column q_k, the basic values, the leaving row p_k -- is an O(m + n) slice of the tableau as it stands in
 // memory, carried through steps 0..k-1 entry by entry with exactly the operations the bulk update would apply
 // (`chain_apply`, the per-entry case analysis of k_fb: pivot row, pivot column, fma elsewhere).  Row 0 and the devex

@@ -26,7 +26,7 @@ constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this co
 constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
 constexpr size_t WT_MIN_BYTES = (size_t)96 << 20, WT_MAX_BYTES = (size_t)272 << 20; // write-through stores in this band (pick_nt)
-constexpr int KCH = 16;          // most pivots one bulk launch of the chained primal path applies (k_fc / k_fbc)
+constexpr int KCH = 16;          // most pivots one bulk launch of the chained primal path applies (k_fcc / k_fcr / k_fbc)
 constexpr int DCH_MAX = 8;  // most dual pivots one k_update applies (dual_chain)
 constexpr int DA_THREADS = 1024; // k_dboot / k_da workgroup size: the O(m) leaving-row pass is redundant per block
 constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
@@ -106,7 +106,7 @@ struct Ctl {
   double *dwx[2];
   int p_nextx[2], p_up_nextx[2];
   int npbd; // number of dual-ratio partials (k_da blocks of DA_THREADS columns)
-  // Chained primal path (k_fc / k_fbc): the pivots after the one k_fa prepared are chosen from O(m + n) slices of the
+  // Chained primal path (k_fcc / k_fcr / k_fbc): the pivots after the one k_fa prepared are chosen from O(m + n) slices of the
   // tableau as it stands -- column q_k and row p_k, carried through the earlier pivots of the chain entry by entry --
   // and ONE bulk launch applies the whole chain (each entry read and written once for up to KCH pivots).  Step 0 of a
   // chain is the step k_fa left in the fields above; ch_*[l] describes step l >= 1 (index 0 is filled for uniform loops).
