@@ -685,10 +685,12 @@ static int leave_flag_for(double lb, double ub, int to_upper) {
 
 enum { R_OPT = 1, R_UNBND, R_NOFEAS, R_ITLIM, R_PFEAS, R_FAIL };
 
-/* One primal iteration for entering column q moving in direction sdir.
+/* Primal ratio test for entering column q moving in direction sdir (nothing is changed).
    phase1: g[i] != 0 marks infeasible basics (+1 below lb, -1 above ub).
-   Returns 0 = pivot/flip done, R_UNBND = no blocking row. */
-static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
+   Returns RT_PIVOT (*p, *p_up, *bt = leaving row, the bound it lands on, the step), RT_FLIP (the entering variable
+   reaches its own other bound first; *bt = 0) or RT_NONE (no blocking row). */
+enum { RT_PIVOT = 0, RT_FLIP = 1, RT_NONE = 2 };
+static int primal_ratio(const orc_prob *P, const ctl_t *ctl, int q, int sdir, const int *g, int *pp, int *pp_up, double *pbt) {
   int m = P->m;
   int p = 0, p_up = 0;
   const int bland = bland_on(ctl);
@@ -726,18 +728,28 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
       p_up = up;
     }
   }
+  *pp = p;
+  *pp_up = p_up;
+  *pbt = bt;
   /* bound flip of the entering variable itself */
   if (P->nlb[q] > -INF && P->nub[q] < INF && P->nflag[q] != ORC_NF) {
     double tf = P->nub[q] - P->nlb[q];
-    if (p == 0 || tf <= bt) {
-      double delta = (sdir > 0) ? tf : -tf;
-      shift_nonbasic(P, q, delta);
-      P->nflag[q] = (sdir > 0) ? ORC_NU : ORC_NL;
-      ctl->stall = 0;
-      return 0;
-    }
+    if (p == 0 || tf <= bt) return RT_FLIP;
   }
-  if (p == 0) return R_UNBND;
+  return p == 0 ? RT_NONE : RT_PIVOT;
+}
+
+/* Carries out what primal_ratio found: the bound flip, or the pivot (p, q) with the devex weight update. */
+static void primal_apply(orc_prob *P, ctl_t *ctl, int kind, int q, int sdir, int p, int p_up, double bt) {
+  const int bland = bland_on(ctl);
+  if (kind == RT_FLIP) {
+    double tf = P->nub[q] - P->nlb[q];
+    double delta = (sdir > 0) ? tf : -tf;
+    shift_nonbasic(P, q, delta);
+    P->nflag[q] = (sdir > 0) ? ORC_NU : ORC_NL;
+    ctl->stall = 0;
+    return;
+  }
   double bound = p_up ? P->bub[p] : P->blb[p];
   if (ctl->pw) {
     double *w = ctl->pw;
@@ -761,6 +773,16 @@ static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
   if (ctl->budget > 0) ctl->budget--;
   if (bland) P->bland_cnt++;
   ctl->stall = (bt <= DEGEN_TOL) ? ctl->stall + 1 : 0;
+}
+
+/* One primal iteration for entering column q moving in direction sdir.
+   Returns 0 = pivot/flip done, R_UNBND = no blocking row. */
+static int primal_step(orc_prob *P, ctl_t *ctl, int q, int sdir, const int *g) {
+  int p, p_up;
+  double bt;
+  const int kind = primal_ratio(P, ctl, q, sdir, g, &p, &p_up, &bt);
+  if (kind == RT_NONE) return R_UNBND;
+  primal_apply(P, ctl, kind, q, sdir, p, p_up, bt);
   return 0;
 }
 
@@ -817,6 +839,25 @@ static void restore_bounds(orc_prob *P, ctl_t *ctl) {
   ctl->perturbed = 0;
 }
 
+/* Score of column j as an entering candidate (devex: d^2 / weight); 0 = not eligible. */
+static int price_col(const orc_prob *P, const double *cost, double sgn, double tol, const double *pw, int j, double *sc, int *sdir) {
+  int f = P->nflag[j];
+  if (f == ORC_NS) return 0;
+  double dj = sgn * cost[j];
+  int up = (f == ORC_NL || f == ORC_NF) && dj > tol;
+  int dn = (f == ORC_NU || f == ORC_NF) && dj < -tol;
+  if (!up && !dn) return 0;
+  *sc = xdiv(dj * dj, pw[j]);
+  *sdir = up ? +1 : -1;
+  return 1;
+}
+
+static int g_mp_cand = 0;
+long long g_mp_major = 0, g_mp_minor = 0;
+void orc_set_mp(int k) { g_mp_cand = k; }
+void orc_mp_stats(long long *out) { out[0] = g_mp_major; out[1] = g_mp_minor; g_mp_major = g_mp_minor = 0; }
+#define MP_MAX 64
+
 static int primal_phase2(orc_prob *P, ctl_t *ctl) {
   double sgn = (P->dir == ORC_MAX) ? 1.0 : -1.0;
   double *w = (double *)xcalloc((size_t)P->n + 1, sizeof(double));
@@ -825,11 +866,62 @@ static int primal_phase2(orc_prob *P, ctl_t *ctl) {
   for (;;) {
     int sdir = 0;
     if (bland_on(ctl) && !ctl->pert_used) perturb_basis(P, ctl);
-    int q = price(P, &TT(P, 0, 0), sgn, ctl->tol_dj, &sdir, bland_on(ctl), w);
     int r = 0;
-    if (q == 0) r = R_OPT;
-    else if (ctl->budget == 0) r = R_ITLIM;
-    else r = primal_step(P, ctl, q, sdir, NULL);
+    const int K = (bland_on(ctl) || g_mp_cand <= 1) ? 1 : (g_mp_cand > MP_MAX ? MP_MAX : g_mp_cand);
+    if (K == 1) {
+      int q = price(P, &TT(P, 0, 0), sgn, ctl->tol_dj, &sdir, bland_on(ctl), w);
+      if (q == 0) r = R_OPT;
+      else if (ctl->budget == 0) r = R_ITLIM;
+      else r = primal_step(P, ctl, q, sdir, NULL);
+    } else {
+      /* multiple pricing: the K best columns of a full pricing pass are the candidates of one major iteration; the
+         minor iterations that follow choose among them only (current reduced costs and weights) */
+      int cand[MP_MAX], nc = 0;
+      double csc[MP_MAX];
+      const double *cost = &TT(P, 0, 0);
+      for (int j = 1; j <= P->n; j++) {
+        double sc;
+        int sd;
+        if (!price_col(P, cost, sgn, ctl->tol_dj, w, j, &sc, &sd)) continue;
+        /* sorted by (score desc, j asc); j ascends, so an equal score goes behind */
+        int pos = nc;
+        while (pos > 0 && sc > csc[pos - 1]) pos--;
+        if (pos >= K) continue;
+        int last = (nc < K) ? nc : K - 1;
+        for (int t = last; t > pos; t--) { cand[t] = cand[t - 1]; csc[t] = csc[t - 1]; }
+        cand[pos] = j;
+        csc[pos] = sc;
+        if (nc < K) nc++;
+      }
+      if (nc == 0) r = R_OPT;
+      else if (ctl->budget == 0) r = R_ITLIM;
+      else {
+        int steps = 0;
+        g_mp_major++;
+        for (;;) {
+          int q = 0, qs = 0, qc = -1;
+          double best = 0.0;
+          for (int t = 0; t < nc; t++) {
+            double sc;
+            int sd;
+            if (cand[t] == 0 || !price_col(P, cost, sgn, ctl->tol_dj, w, cand[t], &sc, &sd)) continue;
+            if (q == 0 || sc > best || (sc == best && cand[t] < q)) { best = sc; q = cand[t]; qs = sd; qc = t; }
+          }
+          if (q == 0) break;
+          if (steps > 0 && (ctl->budget == 0 || bland_on(ctl))) break;
+          int p, p_up;
+          double bt;
+          const int kind = primal_ratio(P, ctl, q, qs, NULL, &p, &p_up, &bt);
+          if (kind == RT_NONE) { if (steps == 0) r = R_UNBND; break; }
+          if (kind == RT_FLIP && steps > 0) break;
+          primal_apply(P, ctl, kind, q, qs, p, p_up, bt);
+          cand[qc] = 0;
+          steps++;
+          g_mp_minor++;
+          if (kind == RT_FLIP || steps == K) break;
+        }
+      }
+    }
     if (r) {
       if (ctl->perturbed) restore_bounds(P, ctl);
       ctl->pw = NULL;
