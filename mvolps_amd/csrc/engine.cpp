@@ -53,6 +53,9 @@ void launch_fb(Ctl *, int m, int n, hipStream_t, int boot = 0);
 void launch_fc(Ctl *, int m, int n, int k, hipStream_t);
 bool chain_supported(int m, int n);
 void launch_fbc(Ctl *, int m, int n, hipStream_t);
+int fcs_row_groups(int m);
+void launch_fcs(Ctl *, int m, int n, int g, int boot, hipStream_t);
+void launch_fbc2(Ctl *, int m, int n, hipStream_t);
 void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
@@ -98,7 +101,11 @@ struct SolveCtx {
   int *d_p1list = nullptr; // phase 1: rows whose infeasibility sign changed
   int *d_tflag = nullptr;  // tableau refresh: target non-basic status by variable number
   double *d_pw[2] = {nullptr, nullptr}; // primal devex weights by column, two sets (fused path ping-pong)
-  double *d_srowk[KCH] = {}, *d_colqk[KCH] = {}; // chained primal path: scaled pivot rows / pivot columns of steps 1..
+  double *d_srowk[KCH] = {}, *d_colqk[KCH] = {}; // chained primal path: scaled pivot rows / pivot columns of the steps
+  // speculative chained path (k_fcs): candidates, their ratio-test partials and columns, the objective row -- two sets each
+  SpecPart *d_sp[2] = {nullptr, nullptr};
+  Cand *d_spr[2] = {nullptr, nullptr};
+  double *d_spcol[2] = {nullptr, nullptr}, *d_drow[2] = {nullptr, nullptr};
   Cand *d_rpc = nullptr;
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
@@ -274,9 +281,17 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_tf = carve((size_t)(mc + l + 1) * 4);
   size_t o_sk[KCH], o_ck[KCH];
   size_t o_rpc = carve((size_t)((mc + 255) / 256 + 1) * sizeof(Cand));
-  for (int k = 1; k < KCH; k++) {
+  for (int k = 0; k < KCH; k++) {
     o_sk[k] = carve((size_t)l * 8);
     o_ck[k] = carve((size_t)(mc + 1) * 8);
+  }
+  const size_t ncb = (size_t)fused_npb(l), nrg = (size_t)std::max(16, fcs_row_groups(mc)); // (the group count is not monotone in m)
+  size_t o_sp[2], o_spr[2], o_spcol[2], o_drow[2];
+  for (int k = 0; k < 2; k++) {
+    o_sp[k] = carve(ncb * sizeof(SpecPart));
+    o_spr[k] = carve(ncb * nrg * sizeof(Cand));
+    o_spcol[k] = carve(ncb * (size_t)(mc + 1) * 8);
+    o_drow[k] = carve((size_t)l * 8);
   }
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
@@ -304,9 +319,15 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_pw[1] = (double *)(b + o_pw1);
   sc.d_tflag = (int *)(b + o_tf);
   sc.d_rpc = (Cand *)(b + o_rpc);
-  for (int k = 1; k < KCH; k++) {
+  for (int k = 0; k < KCH; k++) {
     sc.d_srowk[k] = (double *)(b + o_sk[k]);
     sc.d_colqk[k] = (double *)(b + o_ck[k]);
+  }
+  for (int k = 0; k < 2; k++) {
+    sc.d_sp[k] = (SpecPart *)(b + o_sp[k]);
+    sc.d_spr[k] = (Cand *)(b + o_spr[k]);
+    sc.d_spcol[k] = (double *)(b + o_spcol[k]);
+    sc.d_drow[k] = (double *)(b + o_drow[k]);
   }
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
@@ -544,10 +565,9 @@ static inline void var_bounds(const mvx_prob *P, int k, double *lb, double *ub) 
   }
 }
 
-// Pivots per bulk launch of the chained primal path.  A chained step costs two small launches (~16-20 us, growing
-// slowly with its position in the chain), a pass over the tableau costs its bytes: the longer the pass, the longer the
-// chain that pays (scripts/chainsweep.py, profiles/r02_chain_sweep.jsonl: 16.8 MB no gain, 33 MB best at 4, 67-151 MB at
-// 8, 268 MB at 10-12 -- 10 keeps the bulk launch above 0.6 of the HBM roofline for 1 % of the rate --, 537 MB at 16).  MVX_CHAIN=1 turns the chaining off, 2..KCH fixes the length.
+// Steps per bulk launch of the chained primal path.  A step costs one small launch (k_fcs), a pass over the tableau
+// costs its bytes: chains pay at every size, the longer the pass the longer the chain (scripts/chainsweep.py).
+// MVX_CHAIN=1 turns the chaining off, 2..KCH fixes the length.
 static int g_chain = -1;
 static int chain_length(const mvx_prob *P) {
   if (g_chain < 0) {
@@ -556,10 +576,7 @@ static int chain_length(const mvx_prob *P) {
   }
   if (g_chain > 0) return g_chain;
   const size_t bytes = (size_t)(P->m + 1) * (size_t)P->ld * 8;
-  if (bytes < ((size_t)24 << 20)) return 1;
-  if (bytes < ((size_t)64 << 20)) return 4;
-  if (bytes < ((size_t)200 << 20)) return 8;
-  if (bytes < ((size_t)400 << 20)) return 10;
+  if (bytes < ((size_t)24 << 20)) return 8;
   return 16;
 }
 
@@ -599,10 +616,17 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   h->pp[0] = sc.d_pp[0]; h->pp[1] = sc.d_pp[1]; h->rp = sc.d_rp;
   h->npb = fused_npb(P->n); h->nrb = 0; // nrb is published by k_fb (its grid height)
   h->fstate = F_OFF;
-  for (int k = 1; k < KCH; k++) {
+  for (int k = 0; k < KCH; k++) {
     h->srowk[k] = sc.d_srowk[k];
     h->colqk[k] = sc.d_colqk[k];
   }
+  for (int k = 0; k < 2; k++) {
+    h->sp[k] = sc.d_sp[k];
+    h->spr[k] = sc.d_spr[k];
+    h->spcol[k] = sc.d_spcol[k];
+    h->drow[k] = sc.d_drow[k];
+  }
+  h->pc_epoch = 1;
   h->rpc = sc.d_rpc;
   h->chain_max = chain_length(P);
   h->dchain_max = dual_chain_length((size_t)(P->m + 1) * (size_t)P->ld * 8 >= ((size_t)16 << 20));
@@ -977,24 +1001,21 @@ static void job_enqueue(Context &c, SolveJob &J) {
         const size_t e_generic = J.ev_used;
         if (J.profiled) J.ev_used += 2;
         if (depth > 0) {
-          launch_fboot(sc.d_ctl, n, sc.stream);
-          launch_fb(sc.d_ctl, m_grid, n, sc.stream, 1);
-          // chained path: k_fcc / k_fcr extend the step k_fa prepared into a chain of up to `kc` pivots that ONE bulk launch
-          // applies, so `depth` pivots take depth / kc passes over the tableau when every chain fills (a chain that
-          // ends early leaves pivots for the next batch)
-          int kc = (J.chain > 1 && chain_supported(m_grid, n)) ? J.chain : 1;
+          // speculative chained path: one k_fcs launch per step (the first one of a call only leaves the candidates),
+          // one bulk launch k_fbc2 per chain of up to `kc` steps, so `depth` pivots take depth / kc passes over the
+          // tableau when every chain fills (a chain that ends early leaves pivots for the next batch)
+          launch_fcs(sc.d_ctl, m_grid, n, 0, 1, sc.stream);
+          const int kc = std::max(1, J.chain);
           for (int left = depth; left > 0;) {
             const int steps = std::min(kc, left); // the last pass of a limited run chains only what the limit leaves
-            launch_fa(sc.d_ctl, n, sc.stream);
-            for (int t = 1; t < steps; t++) launch_fc(sc.d_ctl, m_grid, n, t, sc.stream);
+            for (int t = 0; t < steps; t++) launch_fcs(sc.d_ctl, m_grid, n, t, 0, sc.stream);
             ev();
-            if (kc > 1) launch_fbc(sc.d_ctl, m_grid, n, sc.stream);
-            else launch_fb(sc.d_ctl, m_grid, n, sc.stream);
+            launch_fbc2(sc.d_ctl, m_grid, n, sc.stream);
             ev();
             left -= steps;
           }
-          // a run that may end on the pivot limit: one more selection that only looks (k_fa reports the limit itself)
-          if (J.parm.it_lim >= 0 && depth >= remaining) launch_fa(sc.d_ctl, n, sc.stream, 1);
+          // a run that may end on the pivot limit: one more step launch, which finds the limit and reports it
+          if (J.parm.it_lim >= 0 && depth >= remaining) launch_fcs(sc.d_ctl, m_grid, n, 0, 0, sc.stream);
         }
         launch_select(sc.d_ctl, sc.stream);
         if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic], sc.stream));

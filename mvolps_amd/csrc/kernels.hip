@@ -2113,6 +2113,534 @@ __global__ __launch_bounds__(256) void k_fbc(Ctl *c) {
   }
 }
 
+// ================================================= speculative chained primal path (k_fcs / k_fbc2)
+// ONE launch per step of a chain.  The two launches per step of the path above exist because a pivot has two grid-wide
+// decisions -- the entering column (over n) and, once that column is known, the leaving row (over m).  Here every
+// column block answers the second question before the first has been asked: after it has carried its columns through
+// the step this launch prepares (objective row, devex weights, statuses), it prices them, takes ITS best column,
+// gathers that column from the tableau as it stands, carries it through the pending chain and runs the ratio test on it
+// -- a complete candidate pivot per block.  The next launch only has to reduce the candidates: the best score wins, and
+// its leaving row, pivot element and column come with it.  Same pivots, same bits as every other path (the reduction
+// keys are total orders; every entry goes through the same operations in the same order).
+//   k_fcs(g)   step g of the pending chain: winner of the candidates left by the previous launch -> row phase (scaled
+//              pivot row, objective row, weights) -> candidates for step g+1.  Grid: column blocks x row groups; a row
+//              group repeats the row phase of its column block and does its share of the rows of the candidate column.
+//              boot = 1: no step, only the candidates (start of a call; the tableau has no chain pending).
+//   k_fbc2     the bulk pass: every entry read and written once for the whole chain; the pivot-column entries of a tile
+//              are wave-uniform and come in through scalar loads, so the kernel needs no LDS and no barrier.
+// Bound flips are steps of the chain (only column 0 and the status of the flipped column change).  A chain ends early
+// on: no candidate, the pivot limit, the stall limit (Bland's rule and the perturbation stay with the generic step), an
+// unbounded ray.
+struct PStep {
+  int kind, p, q, lf;
+  double piv, xq, s0, delta;
+};
+// entry (i, j) with value v before step st -> after it; ci = entry of row i in the step's pivot column, sj = entry of
+// column j in its scaled pivot row
+__device__ __forceinline__ double papply(const PStep &st, int i, int j, double v, double ci, double sj) {
+  if (st.kind == ST_FLIP) return (j == 0) ? fma(ci, st.delta, v) : v;
+  if (i == st.p) return (j == st.q) ? xdiv(1.0, st.piv) : ((j == 0) ? st.xq - sj : -sj);
+  if (j == st.q) return xdiv(ci, st.piv);
+  return fma(-ci, sj, v);
+}
+struct PView { // the pending chain as every lane needs it (one copy per block, in LDS)
+  PStep st[KCH];
+  double elb[KCH], eub[KCH], llb[KCH], lub[KCH];
+  const double *cq[KCH];
+};
+
+template <int U, int SB> // U rows per lane in the column phase, SB chain steps per batch of carry loads
+__global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
+  __shared__ Cand lds[17];
+  __shared__ PView v;
+  __shared__ double s_sq[KCH], s_cp[KCH], s_own[5];
+  const int ncb = (int)gridDim.x, R = (int)gridDim.y, b = (int)blockIdx.x, rg = (int)blockIdx.y;
+  const bool lead = (b == 0 && rg == 0 && TIDX == 0);
+  const int lane = TIDX & 63;
+  // ---- level 1: the control block, the candidates, this lane's column
+  const int done = c->done, fstate = c->fstate, base = c->curA, epoch = c->pc_epoch;
+  const int m = c->m, n = c->n, mcap1 = c->m_cap + 1;
+  const size_t ld = (size_t)c->ld;
+  double *const T = c->T;
+  const double tol = c->tol_dj, sgn = c->sgn, tp = c->tol_piv;
+  const int budget = c->budget, stall_limit = c->stall_limit;
+  if (done != D_RUN) return;
+  const int j = b * 256 + TIDX;
+  const bool act = (j <= n);
+  int xw;          // the set this launch writes
+  int nsteps = 0;  // steps the candidate column is carried through
+  double dnew = 0.0, wnew = 1.0, lbj = 0.0, ubj = 0.0, sj = 0.0;
+  int fnew = MVX_NS;
+  double sl[KCH]; // this lane's entries of the pending chain's scaled pivot rows
+#pragma unroll
+  for (int l = 0; l < KCH; l++) sl[l] = 0.0;
+  const double *beta0; // basic values the candidates start from
+  size_t beta_stride;
+  if (boot) {
+    const int phase = c->phase;
+    const bool fresh = (phase == PH_START);
+    if (c->stall >= stall_limit || !(phase == PH_PRIMAL2 || (fresh && c->n_edits == 0))) { // no Bland pricing here
+      if (lead) c->fstate = F_OFF;
+      return;
+    }
+    if (fresh) { // select_step's opening check: is the starting basis primal feasible?
+      const double tolb = c->tol_bnd;
+      const double *blb = c->blb, *bub = c->bub;
+      int bad = 0;
+      for (int i0 = 1 + TIDX; i0 <= m; i0 += 256 * 8) {
+        double be[8], lb[8], ub[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = i0 + 256 * u;
+          const bool in = (i <= m);
+          be[u] = in ? T[(size_t)i * ld] : 0.0;
+          lb[u] = in ? blb[i] : -INFINITY;
+          ub[u] = in ? bub[i] : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (lb[u] > -INFINITY && be[u] < lb[u] - tolb * (1.0 + fabs(lb[u]))) bad = 1;
+          if (ub[u] < INFINITY && be[u] > ub[u] + tolb * (1.0 + fabs(ub[u]))) bad = 1;
+        }
+      }
+      if (__syncthreads_or(bad)) { // the generic step decides between the dual simplex and phase 1
+        if (lead) c->fstate = F_OFF;
+        return;
+      }
+    }
+    xw = base & 1;
+    if (act) {
+      dnew = T[j];
+      wnew = fresh ? 1.0 : c->pw[xw][j];
+      if (j >= 1) {
+        fnew = c->nflag[j];
+        lbj = c->nlb[j];
+        ubj = c->nub[j];
+      }
+      if (rg == 0) {
+        c->drow[xw][j] = dnew;
+        c->pw[xw][j] = wnew;
+      }
+    }
+    beta0 = T;
+    beta_stride = ld;
+    if (lead) {
+      c->fstate = F_RUN;
+      c->step = ST_NONE;
+      c->pc_n = 0;
+    }
+  } else {
+    if (fstate != F_RUN) return;
+    if (g > 0 && c->ch_ok[g - 1] != epoch) return; // the chain ended before this step
+    const int xr = (base + g) & 1;
+    xw = xr ^ 1;
+    const int stall = g ? c->ch_stall[g - 1] : c->stall;
+    const int used = g ? c->ch_cnt[g - 1] : 0;
+    // candidates: every wave reduces them on its own (no barrier); a lane keeps the whole record of its best one
+    SpecPart mine{0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0};
+    Cand myr{0.0, 0.0, 0, 0};
+    int myb = 0;
+    {
+      const SpecPart *sp = c->sp[xr];
+      const Cand *spr = c->spr[xr];
+      for (int t = lane; t < ncb; t += 64) {
+        const SpecPart x = sp[t];
+        Cand rr = spr[(size_t)t * R];
+        for (int k = 1; k < R; k++) {
+          const Cand y = spr[(size_t)t * R + k];
+          if (cand_better<1>(y, rr)) rr = y;
+        }
+        if (x.q != 0 && (mine.q == 0 || x.score > mine.score || (x.score == mine.score && x.q < mine.q))) {
+          mine = x;
+          myr = rr;
+          myb = t;
+        }
+      }
+    }
+    // this lane's column as the last step left it, and its entries of the chain's scaled pivot rows
+    double dj = 0.0, wj = 1.0;
+    int fj = MVX_NS;
+    if (act) {
+      dj = c->drow[xr][j];
+      wj = c->pw[xr][j];
+      if (j >= 1) {
+        fj = c->nflag[j];
+        lbj = c->nlb[j];
+        ubj = c->nub[j];
+      }
+#pragma unroll
+      for (int l = 0; l < KCH; l++)
+        if (l < g) sl[l] = c->srowk[l][j];
+    }
+    // the chain so far: one lane per step fetches its record
+    PStep rst{};
+    double relb = 0.0, reub = 0.0, rllb = 0.0, rlub = 0.0;
+    const double *rcq = nullptr;
+    if (TIDX < g) {
+      const int l = TIDX;
+      rst = PStep{c->ch_kind[l], c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l], c->ch_delta[l]};
+      relb = c->ch_elb[l];
+      reub = c->ch_eub[l];
+      rllb = c->ch_llb[l];
+      rlub = c->ch_lub[l];
+      rcq = c->colqk[l];
+    }
+    // winner
+    Cand key{mine.q ? mine.score : 0.0, 0.0, mine.q, lane};
+    key = wave_bcast_best<0>(key);
+    const int q = key.idx, wl = key.aux;
+    const bool none = (q == 0);
+    const int left = (budget < 0) ? 1 : budget - used;
+    if (none || left <= 0 || stall >= stall_limit) {
+      if (lead) {
+        if (g == 0) {
+          c->fstate = F_STOP;
+          c->phase = PH_PRIMAL2;
+          // the pivot limit with an entering column still on offer and nothing perturbed is what the generic step
+          // would report as it stands (select_step: price, then `budget == 0` -> D_ITLIM)
+          if (!none && left <= 0 && stall < stall_limit && !c->perturbed) {
+            c->done = D_ITLIM;
+            c->step = ST_NONE;
+          }
+        }
+      }
+      return;
+    }
+    const int sdir = __shfl(mine.sdir, wl, 64), bwin = __shfl(myb, wl, 64), fq = __shfl(mine.fq, wl, 64);
+    const double dq = __shfl(mine.dq, wl, 64), wq = __shfl(mine.wq, wl, 64), lbq = __shfl(mine.lbq, wl, 64), ubq = __shfl(mine.ubq, wl, 64);
+    const int p = __shfl(myr.idx, wl, 64), p_up = __shfl(myr.aux, wl, 64);
+    const double tstep = __shfl(myr.k1, wl, 64);
+    bool flip = false;
+    double tf = 0.0;
+    if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+      tf = ubq - lbq;
+      if (p == 0 || tf <= tstep) flip = true;
+    }
+    if (!flip && p == 0) { // unbounded ray: the generic path reports it
+      if (lead && g == 0) {
+        c->fstate = F_STOP;
+        c->phase = PH_PRIMAL2;
+      }
+      return;
+    }
+    const double *const colw = c->spcol[xr] + (size_t)bwin * mcap1; // the winner's column as of this step
+    // ---- level 2: what depends on the winner
+    const int pr = flip ? 1 : p;
+    const double piv = colw[pr];
+    const double val0 = (act && !flip) ? T[(size_t)pr * ld + j] : 0.0;
+    const double val00 = T[(size_t)pr * ld]; // the leaving row's basic value: every block works out s_0 for itself
+    double plb = c->blb[pr], pub = c->bub[pr];
+    if (TIDX < g) s_cp[TIDX] = rcq[pr];
+    if (TIDX < g) {
+      v.st[TIDX] = rst;
+      v.elb[TIDX] = relb;
+      v.eub[TIDX] = reub;
+      v.llb[TIDX] = rllb;
+      v.lub[TIDX] = rlub;
+      v.cq[TIDX] = rcq;
+    }
+    __syncthreads();
+    // statuses / bounds as the chain so far left them
+    for (int l = 0; l < g; l++) {
+      if (v.st[l].q == j) {
+        fj = v.st[l].lf;
+        if (v.st[l].kind == ST_PIVOT) {
+          lbj = v.llb[l];
+          ubj = v.lub[l];
+        }
+      }
+      if (v.st[l].kind == ST_PIVOT && v.st[l].p == pr) {
+        plb = v.elb[l];
+        pub = v.eub[l];
+      }
+    }
+    PStep cur{};
+    double cur_elb = lbq, cur_eub = ubq;
+    int stall_new;
+    if (flip) {
+      const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
+      const double delta = (sdir > 0) ? tf : -tf;
+      cur = PStep{ST_FLIP, 0, q, nf, 1.0, 0.0, 0.0, delta};
+      dnew = (j == 0) ? fma(dq, delta, dj) : dj; // the objective value moves with the flipped variable
+      wnew = wj;
+      fnew = (j == q) ? nf : fj;
+      sj = 0.0;
+      stall_new = 0;
+    } else {
+      const double bound = p_up ? pub : plb;
+      const int lf = dev_leave_flag(plb, pub, p_up);
+      double val = val0;
+#pragma unroll
+      for (int l = 0; l < KCH; l++)
+        if (l < g) val = papply(v.st[l], p, j, val, s_cp[l], sl[l]);
+      sj = (j == 0) ? xdiv(val - bound, piv) : xdiv(val, piv);
+      dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dj);
+      if (j == q) {
+        const double cc = xdiv(wq, piv * piv);
+        wnew = cc > 1.0 ? cc : 1.0;
+        lbj = plb; // the leaving variable comes to sit in column q
+        ubj = pub;
+      } else {
+        const double cc = sj * sj * wq;
+        wnew = cc > wj ? cc : wj;
+      }
+      fnew = (j == q) ? lf : fj;
+      double v00 = val00;
+      for (int l = 0; l < g; l++) v00 = papply(v.st[l], p, 0, v00, s_cp[l], v.st[l].s0);
+      const double s0 = xdiv(v00 - bound, piv); // what lane 0 of block 0 gets for column 0
+      cur = PStep{ST_PIVOT, p, q, lf, piv, dev_nb_value(fq, lbq, ubq), s0, 0.0};
+      stall_new = (tstep <= DEGEN_TOL) ? stall + 1 : 0;
+      if (lead) {
+        c->ch_llb[g] = plb;
+        c->ch_lub[g] = pub;
+        c->ch_bound[g] = bound;
+        c->ch_pup[g] = p_up;
+      }
+    }
+    if (act && rg == 0) {
+      c->srowk[g][j] = sj;
+      c->drow[xw][j] = dnew;
+      c->pw[xw][j] = (j >= 1) ? wnew : 1.0;
+    }
+    // the winner's column joins the chain: every workgroup copies a slice of it
+    {
+      double *ck = c->colqk[g];
+      const int wid = rg * ncb + b, tot = ncb * R;
+      for (int i = wid * 256 + TIDX; i <= m; i += tot * 256) ck[i] = colw[i];
+    }
+    if (lead) {
+      c->ch_kind[g] = cur.kind;
+      c->ch_p[g] = cur.p;
+      c->ch_q[g] = cur.q;
+      c->ch_lf[g] = cur.lf;
+      c->ch_piv[g] = cur.piv;
+      c->ch_xq[g] = cur.xq;
+      c->ch_s0[g] = cur.s0;
+      c->ch_delta[g] = cur.delta;
+      c->ch_elb[g] = cur_elb;
+      c->ch_eub[g] = cur_eub;
+      c->ch_stall[g] = stall_new;
+      c->ch_cnt[g] = used + (flip ? 0 : 1);
+      c->ch_ok[g] = epoch;
+      c->pc_n = g + 1;
+      c->phase = PH_PRIMAL2;
+    }
+    // the step itself becomes entry g of the view the candidate column is carried through
+    if (TIDX == 0) {
+      v.st[g] = cur;
+      v.elb[g] = cur_elb;
+      v.eub[g] = cur_eub;
+      v.cq[g] = colw;
+    }
+    nsteps = g + 1;
+    beta0 = c->betac[0];
+    beta_stride = 1;
+  }
+  // ---- level 3: the candidate of this column block for the next step
+  Cand best{0.0, 0.0, 0, 0};
+  if (act && j >= 1) {
+    Cand x{0.0, 0.0, 0, 0};
+    if (price_col(fnew, sgn * dnew, tol, j, wnew, x)) best = x;
+  }
+  best = block_best<0>(best, lds); // (its barriers also publish v.st[g])
+  const int q2 = best.idx, sd2 = best.aux;
+  if (q2 == 0) {
+    if (TIDX == 0) {
+      c->spr[xw][(size_t)b * R + rg] = Cand{0.0, 0.0, 0, 0};
+      if (rg == 0) c->sp[xw][b] = SpecPart{0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0};
+    }
+    return;
+  }
+  if (act && j == q2) { // the lane that owns the candidate column hands out what the others need of it
+    s_own[0] = dnew;
+    s_own[1] = wnew;
+    s_own[2] = lbj;
+    s_own[3] = ubj;
+    s_own[4] = (double)fnew;
+#pragma unroll
+    for (int l = 0; l < KCH; l++)
+      if (l + 1 < nsteps) s_sq[l] = sl[l];
+    if (nsteps > 0) s_sq[nsteps - 1] = sj;
+  }
+  __syncthreads();
+  {
+    const double *blb = c->blb, *bub = c->bub;
+    double a[U], be[U], lb[U], ub[U];
+    int ri[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = 1 + rg * (256 * U) + TIDX + 256 * u;
+      ri[u] = (i <= m) ? i : 0;
+      a[u] = ri[u] ? T[(size_t)i * ld + q2] : 0.0;
+      be[u] = ri[u] ? beta0[(size_t)i * beta_stride] : 0.0;
+      lb[u] = ri[u] ? blb[i] : 0.0;
+      ub[u] = ri[u] ? bub[i] : 0.0;
+    }
+    for (int l0 = 0; l0 < nsteps; l0 += SB) {
+      double ci[SB][U];
+#pragma unroll
+      for (int s = 0; s < SB; s++) {
+        const double *cq = (l0 + s < nsteps) ? v.cq[l0 + s] : nullptr;
+#pragma unroll
+        for (int u = 0; u < U; u++) ci[s][u] = (cq && ri[u]) ? cq[ri[u]] : 0.0;
+      }
+#pragma unroll
+      for (int s = 0; s < SB; s++) {
+        const int l = l0 + s;
+        if (l < nsteps) {
+          const PStep st = v.st[l];
+          const double sq = s_sq[l];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            a[u] = papply(st, ri[u], q2, a[u], ci[s][u], sq);
+            be[u] = papply(st, ri[u], 0, be[u], ci[s][u], st.s0);
+            if (st.kind == ST_PIVOT && st.p == ri[u]) {
+              lb[u] = v.elb[l];
+              ub[u] = v.eub[l];
+            }
+          }
+        }
+      }
+    }
+    double *colo = c->spcol[xw] + (size_t)b * mcap1;
+    Cand rb{0.0, 0.0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (ri[u]) {
+        colo[ri[u]] = a[u];
+        if (boot && b == 0) c->betac[0][ri[u]] = be[u];
+        Cand x{0.0, 0.0, 0, 0};
+        if (ratio_row(a[u], sd2, be[u], lb[u], ub[u], 0, tp, ri[u], x) && cand_better<1>(x, rb)) rb = x;
+      }
+    }
+    rb = block_best<1>(rb, lds);
+    if (TIDX == 0) {
+      c->spr[xw][(size_t)b * R + rg] = rb;
+      if (rg == 0) {
+        colo[0] = s_own[0];
+        c->sp[xw][b] = SpecPart{best.k1, q2, sd2, s_own[0], s_own[1], s_own[2], s_own[3], (int)s_own[4], 0};
+      }
+    }
+  }
+}
+
+// The bulk pass of a chain.  Every entry is loaded once, goes through the chain's steps in registers and is stored
+// once.  What a step needs besides the entry -- the pivot-column entries of the tile's rows, the step's description --
+// is the same for every lane: it comes in through scalar loads (the pointers are read from the control block, the
+// loads happen before any store of this kernel) and sits in SGPRs, so there is no LDS staging and no barrier, and the
+// register budget leaves room for more waves per SIMD than k_fbc had.
+typedef const double __attribute__((address_space(4))) *kconst_f64; // read-only for the whole launch: scalar loads
+template <int TR, int NT>
+__global__ __launch_bounds__(256) void k_fbc2(Ctl *c) {
+  if (c->done != D_RUN || c->fstate != F_RUN) return;
+  const int nch = c->pc_n;
+  if (nch == 0) return;
+  const int n = c->n;
+  const size_t ld = (size_t)c->ld;
+  const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
+  const int i0 = 1 + (int)blockIdx.y * TR;
+  const bool has0 = (j0 == 0);
+  const int xf = (c->curA + nch) & 1; // the set the chain's last step wrote
+  if (j0 <= n) {
+    double *base = c->T + (size_t)i0 * ld + j0;
+    double2 v[TR];
+#pragma unroll
+    for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
+    for (int l = 0; l < nch; l++) {
+      const kconst_f64 cq = (kconst_f64)(c->colqk[l] + i0);
+      const int kind = c->ch_kind[l];
+      if (kind == ST_FLIP) { // only column 0 moves
+        if (has0) {
+          const double delta = c->ch_delta[l];
+#pragma unroll
+          for (int r = 0; r < TR; r++) v[r].x = fma(cq[r], delta, v[r].x);
+        }
+        continue;
+      }
+      const double2 s = *reinterpret_cast<const double2 *>(c->srowk[l] + j0);
+      const int p = c->ch_p[l], q = c->ch_q[l];
+      double ci[TR];
+#pragma unroll
+      for (int r = 0; r < TR; r++) ci[r] = cq[r];
+#pragma unroll
+      for (int r = 0; r < TR; r++) {
+        v[r].x = fma(-ci[r], s.x, v[r].x);
+        v[r].y = fma(-ci[r], s.y, v[r].y);
+      }
+      const bool q0 = (j0 == q), q1 = (j0 + 1 == q);
+      if (q0 || q1) {
+        const double piv = c->ch_piv[l];
+#pragma unroll
+        for (int r = 0; r < TR; r++) {
+          const double qv = xdiv(ci[r], piv);
+          if (q0) v[r].x = qv;
+          if (q1) v[r].y = qv;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (p >= i0 && p < i0 + TR) {
+        const double piv = c->ch_piv[l], xq = c->ch_xq[l];
+#pragma unroll
+        for (int r = 0; r < TR; r++) {
+          if (i0 + r == p) {
+            v[r].x = q0 ? xdiv(1.0, piv) : -s.x;
+            v[r].y = q1 ? xdiv(1.0, piv) : -s.y;
+            if (has0) v[r].x = xq - s.x;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
+    if (has0) {
+      double *bnew = c->betac[0];
+#pragma unroll
+      for (int r = 0; r < TR; r++) bnew[i0 + r] = v[r].x;
+    }
+    if (blockIdx.y == 0) { // the objective row lives outside the row blocks: back into the tableau
+      const double2 d = *reinterpret_cast<const double2 *>(c->drow[xf] + j0);
+      *reinterpret_cast<double2 *>(c->T + j0) = d;
+    }
+  }
+  // The chain's bookkeeping is committed by whichever workgroup finishes last: every other one has read what it needs
+  // of the control block by then (they read it on entry).
+  if (NT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (TIDX == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned t = atomicAdd(&c->pc_arrive, 1u);
+    if (t == total - 1) {
+      for (int l = 0; l < nch; l++) { // the basis swaps of the chain, in order
+        const int q = c->ch_q[l];
+        if (c->ch_kind[l] == ST_FLIP) {
+          c->nflag[q] = c->ch_lf[l];
+          continue;
+        }
+        const int p = c->ch_p[l];
+        const int kv = c->bvar[p];
+        const double klb = c->blb[p], kub = c->bub[p];
+        c->bvar[p] = c->nvar[q];
+        c->blb[p] = c->nlb[q];
+        c->bub[p] = c->nub[q];
+        c->nvar[q] = kv;
+        c->nlb[q] = klb;
+        c->nub[q] = kub;
+        c->nflag[q] = c->ch_lf[l];
+      }
+      const int piv_n = c->ch_cnt[nch - 1];
+      c->it_cnt += piv_n;
+      c->n_flips += nch - piv_n;
+      c->n_bulk++;
+      if (c->budget > 0) c->budget -= piv_n;
+      c->stall = c->ch_stall[nch - 1];
+      c->curA += nch;
+      c->pc_n = 0;
+      c->pc_epoch++;
+      c->pc_arrive = 0;
+    }
+  }
+}
+
 // ======================================================================= fused dual path
 // The dual simplex (every warm start of a B&B child, bs.cpp:279,287) as the same two multi-workgroup kernels per pivot:
 //   k_da  (one block per 256 columns): the entering column q is the reduction of the dual-ratio partials left by the
@@ -2966,6 +3494,41 @@ void launch_fbc(Ctl *d_ctl, int m, int n, hipStream_t s) {
   FBC_CASE(16, 0) FBC_CASE(16, 1) FBC_CASE(16, 2) FBC_CASE(8, 0) FBC_CASE(8, 1) FBC_CASE(8, 2) FBC_CASE(4, 0) FBC_CASE(4, 1) FBC_CASE(4, 2)
 #undef FBC_CASE
   std::abort(); // unreachable: chain_supported() gates the call
+}
+// speculative chained primal path: row groups of the candidate column phase (4 rows per lane up to 16 groups, then 16)
+static void fcs_shape(int m, int *U, int *R) {
+  int r = (m + 1023) / 1024;
+  if (r <= 16) {
+    *U = 4;
+    *R = r < 1 ? 1 : r;
+  } else {
+    *U = 16;
+    *R = (m + 4095) / 4096;
+  }
+}
+int fcs_row_groups(int m) {
+  int U, R;
+  fcs_shape(m, &U, &R);
+  return R;
+}
+void launch_fcs(Ctl *d_ctl, int m, int n, int g, int boot, hipStream_t s) {
+  int U, R;
+  fcs_shape(m, &U, &R);
+  dim3 grid(fused_npb(n), R);
+  if (U == 4) hipLaunchKernelGGL((k_fcs<4, 4>), grid, dim3(256), 0, s, d_ctl, g, boot);
+  else hipLaunchKernelGGL((k_fcs<16, 1>), grid, dim3(256), 0, s, d_ctl, g, boot);
+}
+void launch_fbc2(Ctl *d_ctl, int m, int n, hipStream_t s) {
+  const int pairs = (n + 2) / 2;
+  int tr = pick_tr(m, n);
+  if (tr > 16) tr = 16;
+  const int nt = pick_nt(m, n);
+  dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
+#define FBC2_CASE(TR_, NT_) \
+  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fbc2<TR_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
+  FBC2_CASE(16, 0) FBC2_CASE(16, 1) FBC2_CASE(16, 2) FBC2_CASE(8, 0) FBC2_CASE(8, 1) FBC2_CASE(8, 2) FBC2_CASE(4, 0) FBC2_CASE(4, 1) FBC2_CASE(4, 2)
+#undef FBC2_CASE
+  std::abort(); // unreachable
 }
 void launch_dboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_dboot, dim3((n + DA_THREADS) / DA_THREADS), dim3(DA_THREADS), 0, s, d_ctl); }
 void launch_da(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_da, dim3((n + DA_THREADS) / DA_THREADS), dim3(DA_THREADS), 0, s, d_ctl); }

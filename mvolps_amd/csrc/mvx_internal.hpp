@@ -26,7 +26,7 @@ constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this co
 constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
 constexpr size_t WT_MIN_BYTES = (size_t)96 << 20, WT_MAX_BYTES = (size_t)272 << 20; // write-through stores in this band (pick_nt)
-constexpr int KCH = 16;          // most pivots one bulk launch of the chained primal path applies (k_fcc / k_fcr / k_fbc)
+constexpr int KCH = 32;          // most steps one bulk launch of the chained primal path applies (k_fcs / k_fbc2)
 constexpr int DCH_MAX = 8;  // most dual pivots one k_update applies (dual_chain)
 constexpr int DA_THREADS = 1024; // k_dboot / k_da workgroup size: the O(m) leaving-row pass is redundant per block
 constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
@@ -45,6 +45,16 @@ enum : int { F_OFF = 0, F_RUN = 1, F_STOP = 2, F_RUN_DUAL = 3 };
 struct Cand {
   double k1, k2;
   int idx, aux;
+};
+
+// What one column block of k_fcs leaves for the next step: its best entering column as the step it has just prepared
+// leaves the tableau (score by devex), with everything the next kernel needs of that column should it win
+// (reduced cost, weight, bounds and status of its variable).  The column itself and its ratio test are in spcol / spr.
+struct SpecPart {
+  double score;
+  int q, sdir;
+  double dq, wq, lbq, ubq;
+  int fq, pad;
 };
 
 
@@ -119,7 +129,21 @@ struct Ctl {
   Cand *rpc; // [ceil(m_cap / 256)] ratio-test partials of k_fcc
   double ch_elb[KCH], ch_eub[KCH]; // bounds of the entering variable (become row p's)
   double ch_llb[KCH], ch_lub[KCH]; // bounds of the leaving variable (become column q's)
-  double *srowk[KCH], *colqk[KCH]; // scaled pivot row / pivot column of step l >= 1 ([0] unused: srow, colqx[curB])
+  double *srowk[KCH], *colqk[KCH]; // scaled pivot row / pivot column of step l
+  // Speculative chained primal path (k_fcs / k_fbc2): ONE launch per step.  Every column block prices its own columns
+  // as the step it has just prepared leaves them and at once gathers its best column, carries it through the pending
+  // chain and runs the ratio test on it; the next launch reduces these candidates to the winner, whose leaving row is
+  // then already known.  Two sets of everything a step hands to the next, alternating with the step count
+  // (set read by step g of a chain = (curA + g) & 1).
+  SpecPart *sp[2]; // [ncb]
+  Cand *spr[2];    // [ncb * R] ratio-test partials of the candidates, one per row group
+  double *spcol[2]; // [ncb][m_cap+1] the candidate columns
+  double *drow[2]; // [ld] objective row
+  int pc_n;        // steps recorded in the pending chain (k_fbc2 applies them and resets it)
+  int pc_epoch;    // chains applied so far + 1
+  unsigned pc_arrive; // k_fbc2: workgroups that have finished (the last one commits the chain's bookkeeping)
+  int ch_kind[KCH], ch_cnt[KCH], ch_ok[KCH]; // ST_PIVOT / ST_FLIP; pivots among steps 0..l; == pc_epoch once step l is recorded
+  double ch_delta[KCH]; // bound flips: the entering variable's move
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots
