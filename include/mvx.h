@@ -138,6 +138,8 @@ int mvx_get_it_cnt(const mvx_prob *P);
 int mvx_get_pert_cnt(const mvx_prob *P);
 /* > 0 overrides the number of consecutive degenerate pivots that arms the rules; 0 = default */
 void mvx_set_stall_limit(int limit);
+/* diagnostic (MVX_FCS_DBG=1): phase stamps of the step kernel's lead workgroup, 8 per chain position; returns rows */
+int mvx_fcs_debug_stamps(unsigned long long *out);
 int mvx_get_bland_cnt(const mvx_prob *P);
 int mvx_term_out(int flag);      /* glp_term_out 2test.cpp:45,53,62 */
 const char *mvx_version(void);   /* glp_version  util.cpp:278 */

@@ -449,6 +449,7 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
 }
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }
 void mvx_set_stall_limit(int limit) { mvx::set_stall_limit(limit); }
+int mvx_fcs_debug_stamps(unsigned long long *out) { return mvx::fcs_debug_stamps(out); }
 void mvx_set_refresh(int check_every, double tol) { mvx::set_refresh(check_every, tol); }
 int mvx_get_refresh_cnt(const mvx_prob *P) { return P->refresh_cnt; }
 double mvx_row_residual(const mvx_prob *P) { return mvx::row_residual(P); }

@@ -627,6 +627,18 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
     h->drow[k] = sc.d_drow[k];
   }
   h->pc_epoch = 1;
+  {
+    static unsigned long long *dbg = nullptr;
+    static bool looked = false;
+    if (!looked) {
+      looked = true;
+      if (std::getenv("MVX_FCS_DBG")) {
+        HIPCHECK(hipMalloc((void **)&dbg, (size_t)(KCH + 1) * 8 * 8));
+        HIPCHECK(hipMemset(dbg, 0, (size_t)(KCH + 1) * 8 * 8));
+      }
+    }
+    h->dbg = dbg;
+  }
   h->rpc = sc.d_rpc;
   h->chain_max = chain_length(P);
   h->dchain_max = dual_chain_length((size_t)(P->m + 1) * (size_t)P->ld * 8 >= ((size_t)16 << 20));
@@ -2160,6 +2172,14 @@ void persist_cycles(unsigned long long *out5) {
   if (!g_ctx || !g_ctx->main.h_pabort) return;
   const unsigned long long *d = (const unsigned long long *)(g_ctx->main.h_pabort + 16);
   for (int k = 0; k < 48; k++) out5[k] = d[k];
+}
+// diagnostic (MVX_FCS_DBG=1): the last phase stamps of k_fcs, 8 per chain position (+1 row for the boot launch), 10 ns ticks
+int fcs_debug_stamps(unsigned long long *out) {
+  Context &c = ctx();
+  if (!c.main.h_ctl || !c.main.h_ctl->dbg) return 0;
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpy(out, c.main.h_ctl->dbg, (size_t)(KCH + 1) * 8 * 8, hipMemcpyDeviceToHost));
+  return KCH + 1;
 }
 void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }

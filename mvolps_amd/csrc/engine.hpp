@@ -39,6 +39,7 @@ void *engine_image_alloc(size_t bytes);
 void engine_image_free(void *p);
 void tuning(int tr, int hot, int nt);
 void set_stall_limit(int limit);
+int fcs_debug_stamps(unsigned long long *out);
 void set_persist(int mode);
 void set_chain(int len);
 void set_dual_chain(int len);

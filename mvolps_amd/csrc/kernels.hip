@@ -2149,11 +2149,19 @@ struct PView { // the pending chain as every lane needs it (one copy per block, 
   const double *cq[KCH];
 };
 
+// one earlier step of the chain applied to the leaving row's entry in column j (the divisions it would take are the
+// same for every lane and are done once per step: ip = 1 / piv, cd = cp / piv)
+__device__ __forceinline__ double prow(const PStep &st, int p, int j, double v, double cp, double t, double ip, double cd) {
+  if (st.kind == ST_FLIP) return (j == 0) ? fma(cp, st.delta, v) : v;
+  if (p == st.p) return (j == st.q) ? ip : ((j == 0) ? st.xq - t : -t);
+  return (j == st.q) ? cd : fma(-cp, t, v);
+}
+
 template <int U, int SB> // U rows per lane in the column phase, SB chain steps per batch of carry loads
 __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
   __shared__ Cand lds[17];
   __shared__ PView v;
-  __shared__ double s_sq[KCH], s_cp[KCH], s_own[5];
+  __shared__ double s_sq[KCH], s_cp[KCH], s_ip[KCH], s_cd[KCH], s_own[5];
   const int ncb = (int)gridDim.x, R = (int)gridDim.y, b = (int)blockIdx.x, rg = (int)blockIdx.y;
   const bool lead = (b == 0 && rg == 0 && TIDX == 0);
   const int lane = TIDX & 63;
@@ -2164,16 +2172,18 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
   double *const T = c->T;
   const double tol = c->tol_dj, sgn = c->sgn, tp = c->tol_piv;
   const int budget = c->budget, stall_limit = c->stall_limit;
+  const double *const sr0 = c->srowk[0];
+  const size_t sstride = (size_t)(c->srowk[1] - c->srowk[0]);
   if (done != D_RUN) return;
   const int j = b * 256 + TIDX;
   const bool act = (j <= n);
+  unsigned long long *const dbg = c->dbg;
+#define FCS_STAMP(k) do { if (dbg && lead) dbg[(size_t)(boot ? KCH : g) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  FCS_STAMP(0);
   int xw;          // the set this launch writes
   int nsteps = 0;  // steps the candidate column is carried through
   double dnew = 0.0, wnew = 1.0, lbj = 0.0, ubj = 0.0, sj = 0.0;
   int fnew = MVX_NS;
-  double sl[KCH]; // this lane's entries of the pending chain's scaled pivot rows
-#pragma unroll
-  for (int l = 0; l < KCH; l++) sl[l] = 0.0;
   const double *beta0; // basic values the candidates start from
   size_t beta_stride;
   if (boot) {
@@ -2257,7 +2267,7 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         }
       }
     }
-    // this lane's column as the last step left it, and its entries of the chain's scaled pivot rows
+    // this lane's column as the last step left it
     double dj = 0.0, wj = 1.0;
     int fj = MVX_NS;
     if (act) {
@@ -2268,9 +2278,6 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         lbj = c->nlb[j];
         ubj = c->nub[j];
       }
-#pragma unroll
-      for (int l = 0; l < KCH; l++)
-        if (l < g) sl[l] = c->srowk[l][j];
     }
     // the chain so far: one lane per step fetches its record
     PStep rst{};
@@ -2324,14 +2331,18 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       return;
     }
     const double *const colw = c->spcol[xr] + (size_t)bwin * mcap1; // the winner's column as of this step
+    FCS_STAMP(1);
     // ---- level 2: what depends on the winner
     const int pr = flip ? 1 : p;
     const double piv = colw[pr];
     const double val0 = (act && !flip) ? T[(size_t)pr * ld + j] : 0.0;
     const double val00 = T[(size_t)pr * ld]; // the leaving row's basic value: every block works out s_0 for itself
     double plb = c->blb[pr], pub = c->bub[pr];
-    if (TIDX < g) s_cp[TIDX] = rcq[pr];
     if (TIDX < g) {
+      const double cp = rcq[pr];
+      s_cp[TIDX] = cp;
+      s_ip[TIDX] = xdiv(1.0, rst.piv);
+      s_cd[TIDX] = xdiv(cp, rst.piv);
       v.st[TIDX] = rst;
       v.elb[TIDX] = relb;
       v.eub[TIDX] = reub;
@@ -2340,6 +2351,7 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       v.cq[TIDX] = rcq;
     }
     __syncthreads();
+    FCS_STAMP(2);
     // statuses / bounds as the chain so far left them
     for (int l = 0; l < g; l++) {
       if (v.st[l].q == j) {
@@ -2355,7 +2367,7 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       }
     }
     PStep cur{};
-    double cur_elb = lbq, cur_eub = ubq;
+    double cur_ip = 1.0;
     int stall_new;
     if (flip) {
       const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
@@ -2369,11 +2381,24 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
     } else {
       const double bound = p_up ? pub : plb;
       const int lf = dev_leave_flag(plb, pub, p_up);
-      double val = val0;
+      // the leaving row's entries in this lane's column and in column 0, carried through the chain so far
+      double val = val0, v00 = val00;
+      for (int l0 = 0; l0 < g; l0 += 4) {
+        double t[4];
 #pragma unroll
-      for (int l = 0; l < KCH; l++)
-        if (l < g) val = papply(v.st[l], p, j, val, s_cp[l], sl[l]);
-      sj = (j == 0) ? xdiv(val - bound, piv) : xdiv(val, piv);
+        for (int s = 0; s < 4; s++) t[s] = (act && l0 + s < g) ? sr0[(size_t)(l0 + s) * sstride + j] : 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int l = l0 + s;
+          if (l < g) {
+            val = prow(v.st[l], p, j, val, s_cp[l], t[s], s_ip[l], s_cd[l]);
+            v00 = prow(v.st[l], p, 0, v00, s_cp[l], v.st[l].s0, 0.0, 0.0);
+          }
+        }
+      }
+      const double s0 = xdiv(v00 - bound, piv); // what lane 0 of block 0 gets for column 0
+      sj = (j == 0) ? s0 : xdiv(val, piv);
+      cur_ip = xdiv(1.0, piv);
       dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dj);
       if (j == q) {
         const double cc = xdiv(wq, piv * piv);
@@ -2385,9 +2410,6 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         wnew = cc > wj ? cc : wj;
       }
       fnew = (j == q) ? lf : fj;
-      double v00 = val00;
-      for (int l = 0; l < g; l++) v00 = papply(v.st[l], p, 0, v00, s_cp[l], v.st[l].s0);
-      const double s0 = xdiv(v00 - bound, piv); // what lane 0 of block 0 gets for column 0
       cur = PStep{ST_PIVOT, p, q, lf, piv, dev_nb_value(fq, lbq, ubq), s0, 0.0};
       stall_new = (tstep <= DEGEN_TOL) ? stall + 1 : 0;
       if (lead) {
@@ -2397,6 +2419,7 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         c->ch_pup[g] = p_up;
       }
     }
+    FCS_STAMP(3);
     if (act && rg == 0) {
       c->srowk[g][j] = sj;
       c->drow[xw][j] = dnew;
@@ -2417,8 +2440,8 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       c->ch_xq[g] = cur.xq;
       c->ch_s0[g] = cur.s0;
       c->ch_delta[g] = cur.delta;
-      c->ch_elb[g] = cur_elb;
-      c->ch_eub[g] = cur_eub;
+      c->ch_elb[g] = lbq;
+      c->ch_eub[g] = ubq;
       c->ch_stall[g] = stall_new;
       c->ch_cnt[g] = used + (flip ? 0 : 1);
       c->ch_ok[g] = epoch;
@@ -2428,9 +2451,10 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
     // the step itself becomes entry g of the view the candidate column is carried through
     if (TIDX == 0) {
       v.st[g] = cur;
-      v.elb[g] = cur_elb;
-      v.eub[g] = cur_eub;
+      v.elb[g] = lbq;
+      v.eub[g] = ubq;
       v.cq[g] = colw;
+      s_ip[g] = cur_ip;
     }
     nsteps = g + 1;
     beta0 = c->betac[0];
@@ -2443,6 +2467,7 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
     if (price_col(fnew, sgn * dnew, tol, j, wnew, x)) best = x;
   }
   best = block_best<0>(best, lds); // (its barriers also publish v.st[g])
+  FCS_STAMP(4);
   const int q2 = best.idx, sd2 = best.aux;
   if (q2 == 0) {
     if (TIDX == 0) {
@@ -2457,12 +2482,9 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
     s_own[2] = lbj;
     s_own[3] = ubj;
     s_own[4] = (double)fnew;
-#pragma unroll
-    for (int l = 0; l < KCH; l++)
-      if (l + 1 < nsteps) s_sq[l] = sl[l];
     if (nsteps > 0) s_sq[nsteps - 1] = sj;
   }
-  __syncthreads();
+  if (TIDX + 1 < nsteps) s_sq[TIDX] = sr0[(size_t)TIDX * sstride + q2]; // the candidate column's entries of the earlier pivot rows
   {
     const double *blb = c->blb, *bub = c->bub;
     double a[U], be[U], lb[U], ub[U];
@@ -2476,6 +2498,8 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       lb[u] = ri[u] ? blb[i] : 0.0;
       ub[u] = ri[u] ? bub[i] : 0.0;
     }
+    __syncthreads(); // s_own, s_sq
+    FCS_STAMP(5);
     for (int l0 = 0; l0 < nsteps; l0 += SB) {
       double ci[SB][U];
 #pragma unroll
@@ -2489,19 +2513,32 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         const int l = l0 + s;
         if (l < nsteps) {
           const PStep st = v.st[l];
-          const double sq = s_sq[l];
+          if (st.kind == ST_FLIP) {
 #pragma unroll
-          for (int u = 0; u < U; u++) {
-            a[u] = papply(st, ri[u], q2, a[u], ci[s][u], sq);
-            be[u] = papply(st, ri[u], 0, be[u], ci[s][u], st.s0);
-            if (st.kind == ST_PIVOT && st.p == ri[u]) {
-              lb[u] = v.elb[l];
-              ub[u] = v.eub[l];
+            for (int u = 0; u < U; u++) be[u] = fma(ci[s][u], st.delta, be[u]);
+          } else {
+            const double sq = s_sq[l];
+            if (st.q == q2) { // the candidate is a column an earlier step of the chain pivoted on (rare)
+              const double ip = s_ip[l];
+              for (int u = 0; u < U; u++) a[u] = (ri[u] == st.p) ? ip : xdiv(ci[s][u], st.piv);
+            } else {
+#pragma unroll
+              for (int u = 0; u < U; u++) a[u] = (ri[u] == st.p) ? -sq : fma(-ci[s][u], sq, a[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              const bool isp = (ri[u] == st.p);
+              be[u] = isp ? st.xq - st.s0 : fma(-ci[s][u], st.s0, be[u]);
+              if (isp) {
+                lb[u] = v.elb[l];
+                ub[u] = v.eub[l];
+              }
             }
           }
         }
       }
     }
+    FCS_STAMP(6);
     double *colo = c->spcol[xw] + (size_t)b * mcap1;
     Cand rb{0.0, 0.0, 0, 0};
 #pragma unroll
@@ -2521,7 +2558,9 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         c->sp[xw][b] = SpecPart{best.k1, q2, sd2, s_own[0], s_own[1], s_own[2], s_own[3], (int)s_own[4], 0};
       }
     }
+    FCS_STAMP(7);
   }
+#undef FCS_STAMP
 }
 
 // The bulk pass of a chain.  Every entry is loaded once, goes through the chain's steps in registers and is stored

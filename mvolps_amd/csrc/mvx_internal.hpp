@@ -144,6 +144,7 @@ struct Ctl {
   unsigned pc_arrive; // k_fbc2: workgroups that have finished (the last one commits the chain's bookkeeping)
   int ch_kind[KCH], ch_cnt[KCH], ch_ok[KCH]; // ST_PIVOT / ST_FLIP; pivots among steps 0..l; == pc_epoch once step l is recorded
   double ch_delta[KCH]; // bound flips: the entering variable's move
+  unsigned long long *dbg; // diagnostic phase stamps of k_fcs (MVX_FCS_DBG=1), nullptr otherwise
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots
