@@ -54,8 +54,8 @@ void launch_fc(Ctl *, int m, int n, int k, hipStream_t);
 bool chain_supported(int m, int n);
 void launch_fbc(Ctl *, int m, int n, hipStream_t);
 int fcs_row_groups(int m);
-void launch_fcs(Ctl *, int m, int n, int g, int boot, hipStream_t);
-void launch_fbc2(Ctl *, int m, int n, hipStream_t);
+void launch_fcs(const FcsArgs &, int g, int boot, hipStream_t);
+void launch_fbc2(const FcsArgs &, hipStream_t);
 void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
@@ -105,7 +105,8 @@ struct SolveCtx {
   // speculative chained path (k_fcs): candidates, their ratio-test partials and columns, the objective row -- two sets each
   SpecPart *d_sp[2] = {nullptr, nullptr};
   Cand *d_spr[2] = {nullptr, nullptr};
-  double *d_spcol[2] = {nullptr, nullptr}, *d_drow[2] = {nullptr, nullptr};
+  double *d_spcol[2] = {nullptr, nullptr}, *d_drow[2] = {nullptr, nullptr}, *d_betak[2] = {nullptr, nullptr};
+  size_t sk_stride = 0, ck_stride = 0; // doubles between the chain's consecutive scaled pivot rows / pivot columns
   Cand *d_rpc = nullptr;
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
   Cand *d_pp[2] = {nullptr, nullptr}, *d_rp = nullptr;
@@ -281,13 +282,12 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_tf = carve((size_t)(mc + l + 1) * 4);
   size_t o_sk[KCH], o_ck[KCH];
   size_t o_rpc = carve((size_t)((mc + 255) / 256 + 1) * sizeof(Cand));
-  for (int k = 0; k < KCH; k++) {
-    o_sk[k] = carve((size_t)l * 8);
-    o_ck[k] = carve((size_t)(mc + 1) * 8);
-  }
+  for (int k = 0; k < KCH; k++) o_sk[k] = carve((size_t)l * 8);
+  for (int k = 0; k < KCH; k++) o_ck[k] = carve((size_t)(mc + 1) * 8);
   const size_t ncb = (size_t)fused_npb(l), nrg = (size_t)std::max(16, fcs_row_groups(mc)); // (the group count is not monotone in m)
-  size_t o_sp[2], o_spr[2], o_spcol[2], o_drow[2];
+  size_t o_sp[2], o_spr[2], o_spcol[2], o_drow[2], o_betak[2];
   for (int k = 0; k < 2; k++) {
+    o_betak[k] = carve((size_t)(mc + 1) * 8);
     o_sp[k] = carve(ncb * sizeof(SpecPart));
     o_spr[k] = carve(ncb * nrg * sizeof(Cand));
     o_spcol[k] = carve(ncb * (size_t)(mc + 1) * 8);
@@ -328,7 +328,10 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
     sc.d_spr[k] = (Cand *)(b + o_spr[k]);
     sc.d_spcol[k] = (double *)(b + o_spcol[k]);
     sc.d_drow[k] = (double *)(b + o_drow[k]);
+    sc.d_betak[k] = (double *)(b + o_betak[k]);
   }
+  sc.sk_stride = (o_sk[1] - o_sk[0]) / 8;
+  sc.ck_stride = (o_ck[1] - o_ck[0]) / 8;
   sc.stage_bytes = stage_size(mc, l);
   HIPCHECK(hipMalloc((void **)&sc.d_stage, sc.stage_bytes));
   HIPCHECK(hipHostMalloc((void **)&sc.h_stage, sc.stage_bytes));
@@ -625,6 +628,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
     h->spr[k] = sc.d_spr[k];
     h->spcol[k] = sc.d_spcol[k];
     h->drow[k] = sc.d_drow[k];
+    h->betak[k] = sc.d_betak[k];
   }
   h->pc_epoch = 1;
   {
@@ -633,8 +637,8 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
     if (!looked) {
       looked = true;
       if (std::getenv("MVX_FCS_DBG")) {
-        HIPCHECK(hipMalloc((void **)&dbg, (size_t)(KCH + 1) * 8 * 8));
-        HIPCHECK(hipMemset(dbg, 0, (size_t)(KCH + 1) * 8 * 8));
+        HIPCHECK(hipMalloc((void **)&dbg, (size_t)(KCH + 2) * 8 * 8));
+        HIPCHECK(hipMemset(dbg, 0, (size_t)(KCH + 2) * 8 * 8));
       }
     }
     h->dbg = dbg;
@@ -880,6 +884,7 @@ struct SolveJob {
   bool persist_queued = false; // this batch of launches contains a k_persist launch (its abort flag is copied back)
   int seen_steps = 0, seen_pivots = 0, seen_bulk = 0;
   int chain = 1, chain0 = 1; // pivots per bulk launch the next batch is queued for / the size rule's choice
+  FcsArgs fargs{};           // what the kernels of the speculative chained path take by value
   size_t ev_used = 0;
   bool profiled = false;
   int rc = 0;
@@ -927,6 +932,22 @@ static void job_begin(Context &c, SolveJob &J) {
   take_edits(P, h);
   upload_ctl(sc);
   HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
+  {
+    FcsArgs &a = J.fargs;
+    a.c = sc.d_ctl;
+    a.T = P->d_T;
+    a.blb = P->d_blb; a.bub = P->d_bub; a.nlb = P->d_nlb; a.nub = P->d_nub; a.nflag = P->d_nflag;
+    for (int k = 0; k < 2; k++) {
+      a.sp[k] = sc.d_sp[k]; a.spr[k] = sc.d_spr[k]; a.spcol[k] = sc.d_spcol[k];
+      a.drow[k] = sc.d_drow[k]; a.pw[k] = sc.d_pw[k]; a.betak[k] = sc.d_betak[k];
+    }
+    a.srow0 = sc.d_srowk[0]; a.colq0 = sc.d_colqk[0];
+    a.sstride = sc.sk_stride; a.cstride = sc.ck_stride;
+    a.m = P->m; a.n = P->n; a.ld = P->ld; a.mcap1 = P->m_cap + 1;
+    a.tol_dj = h->tol_dj; a.tol_piv = h->tol_piv; a.tol_bnd = h->tol_bnd; a.sgn = h->sgn;
+    a.stall_limit = h->stall_limit;
+    a.ncb = fused_npb(P->n); a.R = fcs_row_groups(P->m);
+  }
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   J.chain = J.chain0 = h->chain_max;
   J.try_dfused = P->hint_dual && dual_fused_worth_it(P);
@@ -1016,18 +1037,19 @@ static void job_enqueue(Context &c, SolveJob &J) {
           // speculative chained path: one k_fcs launch per step (the first one of a call only leaves the candidates),
           // one bulk launch k_fbc2 per chain of up to `kc` steps, so `depth` pivots take depth / kc passes over the
           // tableau when every chain fills (a chain that ends early leaves pivots for the next batch)
-          launch_fcs(sc.d_ctl, m_grid, n, 0, 1, sc.stream);
+          J.fargs.m = m_grid;
+          launch_fcs(J.fargs, 0, 1, sc.stream);
           const int kc = std::max(1, J.chain);
           for (int left = depth; left > 0;) {
             const int steps = std::min(kc, left); // the last pass of a limited run chains only what the limit leaves
-            for (int t = 0; t < steps; t++) launch_fcs(sc.d_ctl, m_grid, n, t, 0, sc.stream);
+            for (int t = 0; t < steps; t++) launch_fcs(J.fargs, t, 0, sc.stream);
             ev();
-            launch_fbc2(sc.d_ctl, m_grid, n, sc.stream);
+            launch_fbc2(J.fargs, sc.stream);
             ev();
             left -= steps;
           }
           // a run that may end on the pivot limit: one more step launch, which finds the limit and reports it
-          if (J.parm.it_lim >= 0 && depth >= remaining) launch_fcs(sc.d_ctl, m_grid, n, 0, 0, sc.stream);
+          if (J.parm.it_lim >= 0 && depth >= remaining) launch_fcs(J.fargs, 0, 0, sc.stream);
         }
         launch_select(sc.d_ctl, sc.stream);
         if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic], sc.stream));
@@ -2178,7 +2200,7 @@ int fcs_debug_stamps(unsigned long long *out) {
   Context &c = ctx();
   if (!c.main.h_ctl || !c.main.h_ctl->dbg) return 0;
   HIPCHECK(hipDeviceSynchronize());
-  HIPCHECK(hipMemcpy(out, c.main.h_ctl->dbg, (size_t)(KCH + 1) * 8 * 8, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(out, c.main.h_ctl->dbg, (size_t)(KCH + 2) * 8 * 8, hipMemcpyDeviceToHost));
   return KCH + 1;
 }
 void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }

@@ -2157,60 +2157,109 @@ __device__ __forceinline__ double prow(const PStep &st, int p, int j, double v, 
   return (j == st.q) ? cd : fma(-cp, t, v);
 }
 
-template <int U, int SB> // U rows per lane in the column phase, SB chain steps per batch of carry loads
-__global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
-  __shared__ Cand lds[17];
-  __shared__ PView v;
-  __shared__ double s_sq[KCH], s_cp[KCH], s_ip[KCH], s_cd[KCH], s_own[5];
+// value of lane `l` (wave-uniform l) in every lane, through the scalar unit: no LDS, no barrier
+__device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ double rl_d(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+// block-wide arg-best with ONE barrier: every wave leaves its best in its own slot, every wave reduces the four slots
+template <int MODE>
+__device__ __forceinline__ Cand block_best1(Cand x, Cand *slots) {
+  x = wave_best<MODE>(x);
+  if ((TIDX & 63) == 0) slots[TIDX >> 6] = x;
+  __syncthreads();
+  Cand r = slots[0];
+#pragma unroll
+  for (int w = 1; w < 4; w++) {
+    const Cand y = slots[w];
+    if (cand_better<MODE>(y, r)) r = y;
+  }
+  return r;
+}
+
+// Every block keeps ONE candidate column alive from step to step: the set a launch reads holds, per block, the column
+// of the block's last candidate carried through every step so far.  When the block's best column is still that one
+// (the usual case for a block that did not win), the new step is applied to the kept column -- no gather, no carry.
+// Only a block whose candidate changed (the winner always) gathers a column from the tableau and carries it through
+// the whole pending chain.
+// How the kernel is laid out follows what the first versions measured (in-kernel stamps, scripts/fcsdbg.py): every load
+// whose address is known on entry is requested on entry, unconditionally (indices are clamped, results masked: a load
+// behind a run-time condition makes the compiler wait for it on the spot); the description of the pending chain sits in
+// the registers of lanes 0..g-1 of every wave and is broadcast with v_readlane (no LDS round trip per step); two
+// barriers in all; every store at the end.
+template <int U> // rows per lane in the column phase
+__global__ __launch_bounds__(256) void k_fcs(const FcsArgs A, int g, int boot) {
+  __shared__ Cand s_best[4], s_ratio[4];
+  __shared__ double s_pay[4][6];
+  Ctl *const c = A.c;
   const int ncb = (int)gridDim.x, R = (int)gridDim.y, b = (int)blockIdx.x, rg = (int)blockIdx.y;
   const bool lead = (b == 0 && rg == 0 && TIDX == 0);
-  const int lane = TIDX & 63;
-  // ---- level 1: the control block, the candidates, this lane's column
-  const int done = c->done, fstate = c->fstate, base = c->curA, epoch = c->pc_epoch;
-  const int m = c->m, n = c->n, mcap1 = c->m_cap + 1;
-  const size_t ld = (size_t)c->ld;
-  double *const T = c->T;
-  const double tol = c->tol_dj, sgn = c->sgn, tp = c->tol_piv;
-  const int budget = c->budget, stall_limit = c->stall_limit;
-  const double *const sr0 = c->srowk[0];
-  const size_t sstride = (size_t)(c->srowk[1] - c->srowk[0]);
-  if (done != D_RUN) return;
+  const int lane = TIDX & 63, wave = TIDX >> 6;
+  const int m = A.m, n = A.n, mcap1 = A.mcap1;
+  const size_t ld = (size_t)A.ld;
+  double *const T = A.T;
+  const double tol = A.tol_dj, sgn = A.sgn, tp = A.tol_piv;
+  const int stall_limit = A.stall_limit;
+  const int xr = g & 1, xw = boot ? 0 : (xr ^ 1); // the sets this launch reads / writes
   const int j = b * 256 + TIDX;
   const bool act = (j <= n);
+  const int jc = act ? j : n; // clamped: loads are unconditional
   unsigned long long *const dbg = c->dbg;
 #define FCS_STAMP(k) do { if (dbg && lead) dbg[(size_t)(boot ? KCH : g) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   FCS_STAMP(0);
-  int xw;          // the set this launch writes
-  int nsteps = 0;  // steps the candidate column is carried through
+  // ---- level 1: everything whose address is known on entry, requested together
+  const int done = c->done, fstate = c->fstate, epoch = c->pc_epoch, budget = c->budget;
+  int ri[U], rc[U]; // this lane's rows (0 = none) / clamped for the loads
+  double a[U], be[U], lb[U], ub[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int i = 1 + rg * (256 * U) + TIDX + 256 * u;
+    ri[u] = (i <= m) ? i : 0;
+    rc[u] = (i <= m) ? i : m;
+    lb[u] = A.blb[rc[u]];
+    ub[u] = A.bub[rc[u]];
+  }
+  int nsteps = 0; // steps of the pending chain once this launch has added its own
   double dnew = 0.0, wnew = 1.0, lbj = 0.0, ubj = 0.0, sj = 0.0;
   int fnew = MVX_NS;
-  const double *beta0; // basic values the candidates start from
-  size_t beta_stride;
+  int cachedq = 0; // the column this block's kept candidate belongs to
+  double cig[U];   // this launch's step: the pivot column's entries of this lane's rows
+#pragma unroll
+  for (int u = 0; u < U; u++) cig[u] = 0.0;
+  // the pending chain, one step per lane (lanes 0..g-1 of every wave), and this launch's own step (uniform)
+  int rk = 0, rp = 0, rq = 0, rlf = 0;
+  double rpiv = 1.0, rxq = 0.0, rs0 = 0.0, rdelta = 0.0, relb = 0.0, reub = 0.0, rllb = 0.0, rlub = 0.0, rip = 1.0;
+  int ck = ST_NONE, cp_ = 0, cq_ = 0;
+  double cpiv = 1.0, cxq = 0.0, cs0 = 0.0, cdelta = 0.0, celb = 0.0, ceub = 0.0, cip = 1.0;
   if (boot) {
+    if (done != D_RUN) return;
     const int phase = c->phase;
     const bool fresh = (phase == PH_START);
     if (c->stall >= stall_limit || !(phase == PH_PRIMAL2 || (fresh && c->n_edits == 0))) { // no Bland pricing here
       if (lead) c->fstate = F_OFF;
       return;
     }
+    const int src = c->curA & 1;
+#pragma unroll
+    for (int u = 0; u < U; u++) be[u] = T[(size_t)rc[u] * ld];
     if (fresh) { // select_step's opening check: is the starting basis primal feasible?
-      const double tolb = c->tol_bnd;
-      const double *blb = c->blb, *bub = c->bub;
+      const double tolb = A.tol_bnd;
       int bad = 0;
       for (int i0 = 1 + TIDX; i0 <= m; i0 += 256 * 8) {
-        double be[8], lb[8], ub[8];
+        double xb[8], xl[8], xu[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const int i = i0 + 256 * u;
-          const bool in = (i <= m);
-          be[u] = in ? T[(size_t)i * ld] : 0.0;
-          lb[u] = in ? blb[i] : -INFINITY;
-          ub[u] = in ? bub[i] : INFINITY;
+          const int ic = (i <= m) ? i : m;
+          xb[u] = T[(size_t)ic * ld];
+          xl[u] = A.blb[ic];
+          xu[u] = A.bub[ic];
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-          if (lb[u] > -INFINITY && be[u] < lb[u] - tolb * (1.0 + fabs(lb[u]))) bad = 1;
-          if (ub[u] < INFINITY && be[u] > ub[u] + tolb * (1.0 + fabs(ub[u]))) bad = 1;
+          if (xl[u] > -INFINITY && xb[u] < xl[u] - tolb * (1.0 + fabs(xl[u]))) bad = 1;
+          if (xu[u] < INFINITY && xb[u] > xu[u] + tolb * (1.0 + fabs(xu[u]))) bad = 1;
         }
       }
       if (__syncthreads_or(bad)) { // the generic step decides between the dual simplex and phase 1
@@ -2218,32 +2267,20 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         return;
       }
     }
-    xw = base & 1;
-    if (act) {
-      dnew = T[j];
-      wnew = fresh ? 1.0 : c->pw[xw][j];
-      if (j >= 1) {
-        fnew = c->nflag[j];
-        lbj = c->nlb[j];
-        ubj = c->nub[j];
-      }
-      if (rg == 0) {
-        c->drow[xw][j] = dnew;
-        c->pw[xw][j] = wnew;
-      }
+    dnew = T[jc];
+    wnew = fresh ? 1.0 : A.pw[src][jc];
+    if (j >= 1) {
+      fnew = A.nflag[jc];
+      lbj = A.nlb[jc];
+      ubj = A.nub[jc];
     }
-    beta0 = T;
-    beta_stride = ld;
     if (lead) {
       c->fstate = F_RUN;
       c->step = ST_NONE;
       c->pc_n = 0;
     }
   } else {
-    if (fstate != F_RUN) return;
-    if (g > 0 && c->ch_ok[g - 1] != epoch) return; // the chain ended before this step
-    const int xr = (base + g) & 1;
-    xw = xr ^ 1;
+    const int okprev = g ? c->ch_ok[g - 1] : 0;
     const int stall = g ? c->ch_stall[g - 1] : c->stall;
     const int used = g ? c->ch_cnt[g - 1] : 0;
     // candidates: every wave reduces them on its own (no barrier); a lane keeps the whole record of its best one
@@ -2251,8 +2288,8 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
     Cand myr{0.0, 0.0, 0, 0};
     int myb = 0;
     {
-      const SpecPart *sp = c->sp[xr];
-      const Cand *spr = c->spr[xr];
+      const SpecPart *sp = A.sp[xr];
+      const Cand *spr = A.spr[xr];
       for (int t = lane; t < ncb; t += 64) {
         const SpecPart x = sp[t];
         Cand rr = spr[(size_t)t * R];
@@ -2267,31 +2304,48 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         }
       }
     }
-    // this lane's column as the last step left it
-    double dj = 0.0, wj = 1.0;
-    int fj = MVX_NS;
-    if (act) {
-      dj = c->drow[xr][j];
-      wj = c->pw[xr][j];
-      if (j >= 1) {
-        fj = c->nflag[j];
-        lbj = c->nlb[j];
-        ubj = c->nub[j];
+    cachedq = A.sp[xr][b].q;
+    // this lane's column as the last step left it; its entries of the chain's scaled pivot rows (all KCH rows of that
+    // buffer exist: the loads need no guard); its rows of the block's kept candidate and of column 0
+    double ta[16], tb[16];
+    const double dj = A.drow[xr][jc], wj = A.pw[xr][jc];
+    int fj = A.nflag[jc];
+    lbj = A.nlb[jc];
+    ubj = A.nub[jc];
+    if (j == 0 || !act) fj = MVX_NS;
+#pragma unroll
+    for (int s = 0; s < 16; s++) ta[s] = A.srow0[(size_t)s * A.sstride + jc];
+    if (g > 16) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) tb[s] = A.srow0[(size_t)(16 + s) * A.sstride + jc];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; s++) tb[s] = 0.0;
+    }
+    {
+      const double *colp = A.spcol[xr] + (size_t)b * mcap1, *bk = A.betak[xr];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        a[u] = colp[rc[u]];
+        be[u] = bk[rc[u]];
       }
     }
-    // the chain so far: one lane per step fetches its record
-    PStep rst{};
-    double relb = 0.0, reub = 0.0, rllb = 0.0, rlub = 0.0;
-    const double *rcq = nullptr;
-    if (TIDX < g) {
-      const int l = TIDX;
-      rst = PStep{c->ch_kind[l], c->ch_p[l], c->ch_q[l], c->ch_lf[l], c->ch_piv[l], c->ch_xq[l], c->ch_s0[l], c->ch_delta[l]};
-      relb = c->ch_elb[l];
-      reub = c->ch_eub[l];
-      rllb = c->ch_llb[l];
-      rlub = c->ch_lub[l];
-      rcq = c->colqk[l];
-    }
+    // the chain so far: lane l of every wave fetches step l (lanes past the chain re-read its last step: no guard)
+    const int rl = (lane < g) ? lane : (g > 0 ? g - 1 : 0);
+    rk = c->ch_kind[rl];
+    rp = c->ch_p[rl];
+    rq = c->ch_q[rl];
+    rlf = c->ch_lf[rl];
+    rpiv = c->ch_piv[rl];
+    rxq = c->ch_xq[rl];
+    rs0 = c->ch_s0[rl];
+    rdelta = c->ch_delta[rl];
+    relb = c->ch_elb[rl];
+    reub = c->ch_eub[rl];
+    rllb = c->ch_llb[rl];
+    rlub = c->ch_lub[rl];
+    if (done != D_RUN || fstate != F_RUN) return;
+    if (g > 0 && okprev != epoch) return; // the chain ended before this step
     // winner
     Cand key{mine.q ? mine.score : 0.0, 0.0, mine.q, lane};
     key = wave_bcast_best<0>(key);
@@ -2313,10 +2367,10 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       }
       return;
     }
-    const int sdir = __shfl(mine.sdir, wl, 64), bwin = __shfl(myb, wl, 64), fq = __shfl(mine.fq, wl, 64);
-    const double dq = __shfl(mine.dq, wl, 64), wq = __shfl(mine.wq, wl, 64), lbq = __shfl(mine.lbq, wl, 64), ubq = __shfl(mine.ubq, wl, 64);
-    const int p = __shfl(myr.idx, wl, 64), p_up = __shfl(myr.aux, wl, 64);
-    const double tstep = __shfl(myr.k1, wl, 64);
+    const int sdir = rl_i(mine.sdir, wl), bwin = rl_i(myb, wl), fq = rl_i(mine.fq, wl);
+    const double dq = rl_d(mine.dq, wl), wq = rl_d(mine.wq, wl), lbq = rl_d(mine.lbq, wl), ubq = rl_d(mine.ubq, wl);
+    const int p = rl_i(myr.idx, wl), p_up = rl_i(myr.aux, wl);
+    const double tstep = rl_d(myr.k1, wl);
     bool flip = false;
     double tf = 0.0;
     if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
@@ -2330,75 +2384,73 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       }
       return;
     }
-    const double *const colw = c->spcol[xr] + (size_t)bwin * mcap1; // the winner's column as of this step
+    const double *const colw = A.spcol[xr] + (size_t)bwin * mcap1; // the winner's column as of this step
     FCS_STAMP(1);
     // ---- level 2: what depends on the winner
     const int pr = flip ? 1 : p;
     const double piv = colw[pr];
-    const double val0 = (act && !flip) ? T[(size_t)pr * ld + j] : 0.0;
-    const double val00 = T[(size_t)pr * ld]; // the leaving row's basic value: every block works out s_0 for itself
-    double plb = c->blb[pr], pub = c->bub[pr];
-    if (TIDX < g) {
-      const double cp = rcq[pr];
-      s_cp[TIDX] = cp;
-      s_ip[TIDX] = xdiv(1.0, rst.piv);
-      s_cd[TIDX] = xdiv(cp, rst.piv);
-      v.st[TIDX] = rst;
-      v.elb[TIDX] = relb;
-      v.eub[TIDX] = reub;
-      v.llb[TIDX] = rllb;
-      v.lub[TIDX] = rlub;
-      v.cq[TIDX] = rcq;
-    }
-    __syncthreads();
+    const double val0 = T[(size_t)pr * ld + jc];
+    const double val00 = A.betak[xr][pr]; // the leaving row's basic value as of this step
+    double plb = A.blb[pr], pub = A.bub[pr];
+#pragma unroll
+    for (int u = 0; u < U; u++) cig[u] = colw[rc[u]];
+    const double rcp = (A.colq0 + (size_t)rl * A.cstride)[pr]; // step l's pivot-column entry of the leaving row
+    rip = xdiv(1.0, rpiv);
+    const double rcd = xdiv(rcp, rpiv);
     FCS_STAMP(2);
-    // statuses / bounds as the chain so far left them
-    for (int l = 0; l < g; l++) {
-      if (v.st[l].q == j) {
-        fj = v.st[l].lf;
-        if (v.st[l].kind == ST_PIVOT) {
-          lbj = v.llb[l];
-          ubj = v.lub[l];
-        }
-      }
-      if (v.st[l].kind == ST_PIVOT && v.st[l].p == pr) {
-        plb = v.elb[l];
-        pub = v.eub[l];
-      }
+    // the leaving row's entry in this lane's column carried through the chain so far; statuses / bounds as the chain
+    // so far left them
+    double val = val0;
+#define FCS_ROWSTEP(S, TV)                                                                                         \
+  if ((S) < g) {                                                                                                   \
+    const int lk = rl_i(rk, (S)), lp = rl_i(rp, (S)), lq = rl_i(rq, (S));                                          \
+    const double cp = rl_d(rcp, (S));                                                                              \
+    if (lk == ST_FLIP) {                                                                                           \
+      if (lq == j) fj = rl_i(rlf, (S));                                                                            \
+    } else {                                                                                                       \
+      if (lp == p) val = (j == lq) ? rl_d(rip, (S)) : ((j == 0) ? rl_d(rxq, (S)) - (TV) : -(TV));                  \
+      else val = (j == lq) ? rl_d(rcd, (S)) : fma(-cp, (TV), val);                                                 \
+      if (lq == j) {                                                                                               \
+        fj = rl_i(rlf, (S));                                                                                       \
+        lbj = rl_d(rllb, (S));                                                                                     \
+        ubj = rl_d(rlub, (S));                                                                                     \
+      }                                                                                                            \
+      if (lp == pr) {                                                                                              \
+        plb = rl_d(relb, (S));                                                                                     \
+        pub = rl_d(reub, (S));                                                                                     \
+      }                                                                                                            \
+      _Pragma("unroll") for (int u = 0; u < U; u++) if (lp == ri[u]) {                                             \
+        lb[u] = rl_d(relb, (S));                                                                                   \
+        ub[u] = rl_d(reub, (S));                                                                                   \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+#pragma unroll
+    for (int s = 0; s < 16; s++) { FCS_ROWSTEP(s, ta[s]) }
+    if (g > 16) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) { FCS_ROWSTEP(16 + s, tb[s]) }
     }
-    PStep cur{};
-    double cur_ip = 1.0;
+#undef FCS_ROWSTEP
     int stall_new;
     if (flip) {
       const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
-      const double delta = (sdir > 0) ? tf : -tf;
-      cur = PStep{ST_FLIP, 0, q, nf, 1.0, 0.0, 0.0, delta};
-      dnew = (j == 0) ? fma(dq, delta, dj) : dj; // the objective value moves with the flipped variable
+      cdelta = (sdir > 0) ? tf : -tf;
+      ck = ST_FLIP;
+      cp_ = 0;
+      cq_ = q;
+      dnew = (j == 0) ? fma(dq, cdelta, dj) : dj; // the objective value moves with the flipped variable
       wnew = wj;
       fnew = (j == q) ? nf : fj;
       sj = 0.0;
       stall_new = 0;
+      if (lead) c->ch_lf[g] = nf;
     } else {
       const double bound = p_up ? pub : plb;
       const int lf = dev_leave_flag(plb, pub, p_up);
-      // the leaving row's entries in this lane's column and in column 0, carried through the chain so far
-      double val = val0, v00 = val00;
-      for (int l0 = 0; l0 < g; l0 += 4) {
-        double t[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) t[s] = (act && l0 + s < g) ? sr0[(size_t)(l0 + s) * sstride + j] : 0.0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int l = l0 + s;
-          if (l < g) {
-            val = prow(v.st[l], p, j, val, s_cp[l], t[s], s_ip[l], s_cd[l]);
-            v00 = prow(v.st[l], p, 0, v00, s_cp[l], v.st[l].s0, 0.0, 0.0);
-          }
-        }
-      }
-      const double s0 = xdiv(v00 - bound, piv); // what lane 0 of block 0 gets for column 0
-      sj = (j == 0) ? s0 : xdiv(val, piv);
-      cur_ip = xdiv(1.0, piv);
+      cs0 = xdiv(val00 - bound, piv); // what lane 0 of block 0 gets for column 0
+      sj = (j == 0) ? cs0 : xdiv(val, piv);
+      cip = xdiv(1.0, piv);
       dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dj);
       if (j == q) {
         const double cc = xdiv(wq, piv * piv);
@@ -2410,36 +2462,32 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
         wnew = cc > wj ? cc : wj;
       }
       fnew = (j == q) ? lf : fj;
-      cur = PStep{ST_PIVOT, p, q, lf, piv, dev_nb_value(fq, lbq, ubq), s0, 0.0};
+      ck = ST_PIVOT;
+      cp_ = p;
+      cq_ = q;
+      cpiv = piv;
+      cxq = dev_nb_value(fq, lbq, ubq);
+      celb = lbq;
+      ceub = ubq;
       stall_new = (tstep <= DEGEN_TOL) ? stall + 1 : 0;
       if (lead) {
+        c->ch_lf[g] = lf;
         c->ch_llb[g] = plb;
         c->ch_lub[g] = pub;
         c->ch_bound[g] = bound;
         c->ch_pup[g] = p_up;
       }
     }
+    if (!act || j == 0) fnew = MVX_NS;
     FCS_STAMP(3);
-    if (act && rg == 0) {
-      c->srowk[g][j] = sj;
-      c->drow[xw][j] = dnew;
-      c->pw[xw][j] = (j >= 1) ? wnew : 1.0;
-    }
-    // the winner's column joins the chain: every workgroup copies a slice of it
-    {
-      double *ck = c->colqk[g];
-      const int wid = rg * ncb + b, tot = ncb * R;
-      for (int i = wid * 256 + TIDX; i <= m; i += tot * 256) ck[i] = colw[i];
-    }
     if (lead) {
-      c->ch_kind[g] = cur.kind;
-      c->ch_p[g] = cur.p;
-      c->ch_q[g] = cur.q;
-      c->ch_lf[g] = cur.lf;
-      c->ch_piv[g] = cur.piv;
-      c->ch_xq[g] = cur.xq;
-      c->ch_s0[g] = cur.s0;
-      c->ch_delta[g] = cur.delta;
+      c->ch_kind[g] = ck;
+      c->ch_p[g] = cp_;
+      c->ch_q[g] = cq_;
+      c->ch_piv[g] = cpiv;
+      c->ch_xq[g] = cxq;
+      c->ch_s0[g] = cs0;
+      c->ch_delta[g] = cdelta;
       c->ch_elb[g] = lbq;
       c->ch_eub[g] = ubq;
       c->ch_stall[g] = stall_new;
@@ -2448,17 +2496,7 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
       c->pc_n = g + 1;
       c->phase = PH_PRIMAL2;
     }
-    // the step itself becomes entry g of the view the candidate column is carried through
-    if (TIDX == 0) {
-      v.st[g] = cur;
-      v.elb[g] = lbq;
-      v.eub[g] = ubq;
-      v.cq[g] = colw;
-      s_ip[g] = cur_ip;
-    }
     nsteps = g + 1;
-    beta0 = c->betac[0];
-    beta_stride = 1;
   }
   // ---- level 3: the candidate of this column block for the next step
   Cand best{0.0, 0.0, 0, 0};
@@ -2466,127 +2504,170 @@ __global__ __launch_bounds__(256) void k_fcs(Ctl *c, int g, int boot) {
     Cand x{0.0, 0.0, 0, 0};
     if (price_col(fnew, sgn * dnew, tol, j, wnew, x)) best = x;
   }
-  best = block_best<0>(best, lds); // (its barriers also publish v.st[g])
+  {
+    // a wave's best column and what the next launch needs of it, taken from the lane that owns it
+    const Cand wb = wave_bcast_best<0>(best);
+    const int ol = wb.idx ? ((wb.idx - b * 256) & 63) : 0;
+    const double p0 = rl_d(dnew, ol), p1 = rl_d(wnew, ol), p2 = rl_d(lbj, ol), p3 = rl_d(ubj, ol), p5 = rl_d(sj, ol);
+    const int p4 = rl_i(fnew, ol);
+    if (lane == 0) {
+      s_best[wave] = wb;
+      s_pay[wave][0] = p0;
+      s_pay[wave][1] = p1;
+      s_pay[wave][2] = p2;
+      s_pay[wave][3] = p3;
+      s_pay[wave][4] = (double)p4;
+      s_pay[wave][5] = p5;
+    }
+  }
+  __syncthreads();
+  int bw = 0;
+  best = s_best[0];
+#pragma unroll
+  for (int w = 1; w < 4; w++) {
+    const Cand y = s_best[w];
+    if (cand_better<0>(y, best)) {
+      best = y;
+      bw = w;
+    }
+  }
   FCS_STAMP(4);
   const int q2 = best.idx, sd2 = best.aux;
-  if (q2 == 0) {
-    if (TIDX == 0) {
-      c->spr[xw][(size_t)b * R + rg] = Cand{0.0, 0.0, 0, 0};
-      if (rg == 0) c->sp[xw][b] = SpecPart{0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0};
-    }
-    return;
-  }
-  if (act && j == q2) { // the lane that owns the candidate column hands out what the others need of it
-    s_own[0] = dnew;
-    s_own[1] = wnew;
-    s_own[2] = lbj;
-    s_own[3] = ubj;
-    s_own[4] = (double)fnew;
-    if (nsteps > 0) s_sq[nsteps - 1] = sj;
-  }
-  if (TIDX + 1 < nsteps) s_sq[TIDX] = sr0[(size_t)TIDX * sstride + q2]; // the candidate column's entries of the earlier pivot rows
-  {
-    const double *blb = c->blb, *bub = c->bub;
-    double a[U], be[U], lb[U], ub[U];
-    int ri[U];
+  const double own_d = s_pay[bw][0], own_w = s_pay[bw][1], own_lb = s_pay[bw][2], own_ub = s_pay[bw][3], own_s = s_pay[bw][5];
+  const int own_f = (int)s_pay[bw][4];
+  double *const colo = A.spcol[xw] + (size_t)b * mcap1;
+  const bool keep = (!boot && q2 != 0 && q2 == cachedq); // the kept candidate column is still the block's best
+  if (dbg && TIDX == 0 && rg == 0 && !boot) atomicAdd(&dbg[(size_t)(KCH + 1) * 8 + (keep ? 0 : (q2 ? 1 : 2))], 1ull);
+  if (q2 != 0 && !keep) {
+    // a fresh column: gathered from the tableau as it stands, carried through the steps before this launch's
+    const int q2c = q2;
+    const double sqv = A.srow0[(size_t)((lane < g) ? lane : 0) * A.sstride + q2c]; // its entries of the earlier pivot rows, one per lane
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = 1 + rg * (256 * U) + TIDX + 256 * u;
-      ri[u] = (i <= m) ? i : 0;
-      a[u] = ri[u] ? T[(size_t)i * ld + q2] : 0.0;
-      be[u] = ri[u] ? beta0[(size_t)i * beta_stride] : 0.0;
-      lb[u] = ri[u] ? blb[i] : 0.0;
-      ub[u] = ri[u] ? bub[i] : 0.0;
-    }
-    __syncthreads(); // s_own, s_sq
-    FCS_STAMP(5);
-    for (int l0 = 0; l0 < nsteps; l0 += SB) {
+    for (int u = 0; u < U; u++) a[u] = T[(size_t)rc[u] * ld + q2c];
+    constexpr int SB = (U <= 2) ? 16 : 2; // steps per batch of carry loads
+    for (int l0 = 0; l0 + 1 < nsteps; l0 += SB) {
       double ci[SB][U];
 #pragma unroll
       for (int s = 0; s < SB; s++) {
-        const double *cq = (l0 + s < nsteps) ? v.cq[l0 + s] : nullptr;
+        const int l = (l0 + s + 1 < nsteps) ? l0 + s : 0;
+        const double *cq = A.colq0 + (size_t)l * A.cstride;
 #pragma unroll
-        for (int u = 0; u < U; u++) ci[s][u] = (cq && ri[u]) ? cq[ri[u]] : 0.0;
+        for (int u = 0; u < U; u++) ci[s][u] = cq[rc[u]];
       }
 #pragma unroll
       for (int s = 0; s < SB; s++) {
         const int l = l0 + s;
-        if (l < nsteps) {
-          const PStep st = v.st[l];
-          if (st.kind == ST_FLIP) {
-#pragma unroll
-            for (int u = 0; u < U; u++) be[u] = fma(ci[s][u], st.delta, be[u]);
-          } else {
-            const double sq = s_sq[l];
-            if (st.q == q2) { // the candidate is a column an earlier step of the chain pivoted on (rare)
-              const double ip = s_ip[l];
-              for (int u = 0; u < U; u++) a[u] = (ri[u] == st.p) ? ip : xdiv(ci[s][u], st.piv);
+        if (l + 1 < nsteps) {
+          const int lk = rl_i(rk, l), lp = rl_i(rp, l), lq = rl_i(rq, l);
+          if (lk == ST_PIVOT) {
+            const double sq = rl_d(sqv, l);
+            if (lq == q2) { // a column an earlier step of the chain pivoted on (rare)
+              const double ip = rl_d(rip, l), pv = rl_d(rpiv, l);
+              for (int u = 0; u < U; u++) a[u] = (ri[u] == lp) ? ip : xdiv(ci[s][u], pv);
             } else {
 #pragma unroll
-              for (int u = 0; u < U; u++) a[u] = (ri[u] == st.p) ? -sq : fma(-ci[s][u], sq, a[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-              const bool isp = (ri[u] == st.p);
-              be[u] = isp ? st.xq - st.s0 : fma(-ci[s][u], st.s0, be[u]);
-              if (isp) {
-                lb[u] = v.elb[l];
-                ub[u] = v.eub[l];
-              }
+              for (int u = 0; u < U; u++) a[u] = (ri[u] == lp) ? -sq : fma(-ci[s][u], sq, a[u]);
             }
           }
         }
       }
     }
-    FCS_STAMP(6);
-    double *colo = c->spcol[xw] + (size_t)b * mcap1;
-    Cand rb{0.0, 0.0, 0, 0};
+  }
+  FCS_STAMP(5);
+  // this launch's own step applied to the candidate column and to column 0
+  if (nsteps > 0) {
+    if (ck == ST_FLIP) {
+#pragma unroll
+      for (int u = 0; u < U; u++) be[u] = fma(cig[u], cdelta, be[u]);
+    } else {
+      if (q2 != 0) {
+        if (cq_ == q2) {
+          for (int u = 0; u < U; u++) a[u] = (ri[u] == cp_) ? cip : xdiv(cig[u], cpiv);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; u++) a[u] = (ri[u] == cp_) ? -own_s : fma(-cig[u], own_s, a[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool isp = (ri[u] == cp_);
+        be[u] = isp ? cxq - cs0 : fma(-cig[u], cs0, be[u]);
+        if (isp) {
+          lb[u] = celb;
+          ub[u] = ceub;
+        }
+      }
+    }
+  }
+  FCS_STAMP(6);
+  Cand rb{0.0, 0.0, 0, 0};
+  if (q2 != 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (ri[u]) {
-        colo[ri[u]] = a[u];
-        if (boot && b == 0) c->betac[0][ri[u]] = be[u];
         Cand x{0.0, 0.0, 0, 0};
         if (ratio_row(a[u], sd2, be[u], lb[u], ub[u], 0, tp, ri[u], x) && cand_better<1>(x, rb)) rb = x;
       }
     }
-    rb = block_best<1>(rb, lds);
-    if (TIDX == 0) {
-      c->spr[xw][(size_t)b * R + rg] = rb;
-      if (rg == 0) {
-        colo[0] = s_own[0];
-        c->sp[xw][b] = SpecPart{best.k1, q2, sd2, s_own[0], s_own[1], s_own[2], s_own[3], (int)s_own[4], 0};
+  }
+  rb = block_best1<1>(rb, s_ratio);
+  // ---- every store of the launch (nothing above waits for one)
+  if (act && rg == 0) {
+    if (boot) {
+      A.drow[0][j] = dnew;
+      A.pw[0][j] = wnew; // both sets current: the generic step reads pw[curA & 1]
+      A.pw[1][j] = wnew;
+    } else {
+      A.srow0[(size_t)g * A.sstride + j] = sj;
+      A.drow[xw][j] = dnew;
+      A.pw[xw][j] = (j >= 1) ? wnew : 1.0;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    if (ri[u]) {
+      if (q2 != 0) colo[ri[u]] = a[u];
+      if (b == 0) {
+        A.betak[xw][ri[u]] = be[u];
+        if (nsteps > 0) A.colq0[(size_t)(nsteps - 1) * A.cstride + ri[u]] = cig[u]; // the step's pivot column joins the chain
       }
     }
-    FCS_STAMP(7);
   }
+  if (TIDX == 0) {
+    A.spr[xw][(size_t)b * R + rg] = rb;
+    if (rg == 0) {
+      if (q2 != 0) {
+        colo[0] = own_d;
+        A.sp[xw][b] = SpecPart{best.k1, q2, sd2, own_d, own_w, own_lb, own_ub, own_f, 0};
+      } else {
+        A.sp[xw][b] = SpecPart{0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0};
+      }
+    }
+  }
+  FCS_STAMP(7);
 #undef FCS_STAMP
 }
 
-// The bulk pass of a chain.  Every entry is loaded once, goes through the chain's steps in registers and is stored
-// once.  What a step needs besides the entry -- the pivot-column entries of the tile's rows, the step's description --
-// is the same for every lane: it comes in through scalar loads (the pointers are read from the control block, the
-// loads happen before any store of this kernel) and sits in SGPRs, so there is no LDS staging and no barrier, and the
-// register budget leaves room for more waves per SIMD than k_fbc had.
 typedef const double __attribute__((address_space(4))) *kconst_f64; // read-only for the whole launch: scalar loads
 template <int TR, int NT>
-__global__ __launch_bounds__(256) void k_fbc2(Ctl *c) {
+__global__ __launch_bounds__(256) void k_fbc2(const FcsArgs A) {
+  Ctl *const c = A.c;
   if (c->done != D_RUN || c->fstate != F_RUN) return;
   const int nch = c->pc_n;
   if (nch == 0) return;
-  const int n = c->n;
-  const size_t ld = (size_t)c->ld;
+  const int n = A.n;
+  const size_t ld = (size_t)A.ld;
   const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
   const int i0 = 1 + (int)blockIdx.y * TR;
   const bool has0 = (j0 == 0);
-  const int xf = (c->curA + nch) & 1; // the set the chain's last step wrote
+  const int xf = nch & 1; // the set the chain's last step wrote
   if (j0 <= n) {
-    double *base = c->T + (size_t)i0 * ld + j0;
+    double *base = A.T + (size_t)i0 * ld + j0;
     double2 v[TR];
 #pragma unroll
     for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
     for (int l = 0; l < nch; l++) {
-      const kconst_f64 cq = (kconst_f64)(c->colqk[l] + i0);
+      const kconst_f64 cq = (kconst_f64)(A.colq0 + (size_t)l * A.cstride + i0);
       const int kind = c->ch_kind[l];
       if (kind == ST_FLIP) { // only column 0 moves
         if (has0) {
@@ -2596,7 +2677,7 @@ __global__ __launch_bounds__(256) void k_fbc2(Ctl *c) {
         }
         continue;
       }
-      const double2 s = *reinterpret_cast<const double2 *>(c->srowk[l] + j0);
+      const double2 s = *reinterpret_cast<const double2 *>(A.srow0 + (size_t)l * A.sstride + j0);
       const int p = c->ch_p[l], q = c->ch_q[l];
       double ci[TR];
 #pragma unroll
@@ -2632,17 +2713,32 @@ __global__ __launch_bounds__(256) void k_fbc2(Ctl *c) {
 #pragma unroll
     for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
     if (has0) {
-      double *bnew = c->betac[0];
+      double *bnew = A.betak[0];
 #pragma unroll
       for (int r = 0; r < TR; r++) bnew[i0 + r] = v[r].x;
     }
     if (blockIdx.y == 0) { // the objective row lives outside the row blocks: back into the tableau
-      const double2 d = *reinterpret_cast<const double2 *>(c->drow[xf] + j0);
-      *reinterpret_cast<double2 *>(c->T + j0) = d;
+      const double2 d = *reinterpret_cast<const double2 *>(A.drow[xf] + j0);
+      *reinterpret_cast<double2 *>(A.T + j0) = d;
+      if (xf == 1) { // the next chain starts from set 0
+        *reinterpret_cast<double2 *>(A.drow[0] + j0) = d;
+        *reinterpret_cast<double2 *>(A.pw[0] + j0) = *reinterpret_cast<const double2 *>(A.pw[1] + j0);
+      }
     }
   }
+  if (xf == 1) { // ... and so do the candidates the chain's last step left
+    const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
+    const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + TIDX;
+    const size_t ncol = (size_t)A.ncb * A.mcap1;
+    for (size_t e = me; e < ncol; e += nthr) A.spcol[0][e] = A.spcol[1][e];
+    const size_t nsp = (size_t)A.ncb * (sizeof(SpecPart) / 8), nspr = (size_t)A.ncb * A.R * (sizeof(Cand) / 8);
+    const double *s1 = reinterpret_cast<const double *>(A.sp[1]), *r1 = reinterpret_cast<const double *>(A.spr[1]);
+    double *s0 = reinterpret_cast<double *>(A.sp[0]), *r0 = reinterpret_cast<double *>(A.spr[0]);
+    for (size_t e = me; e < nsp; e += nthr) s0[e] = s1[e];
+    for (size_t e = me; e < nspr; e += nthr) r0[e] = r1[e];
+  }
   // The chain's bookkeeping is committed by whichever workgroup finishes last: every other one has read what it needs
-  // of the control block by then (they read it on entry).
+  // of the control block by then.
   if (NT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (TIDX == 0) {
@@ -2652,19 +2748,19 @@ __global__ __launch_bounds__(256) void k_fbc2(Ctl *c) {
       for (int l = 0; l < nch; l++) { // the basis swaps of the chain, in order
         const int q = c->ch_q[l];
         if (c->ch_kind[l] == ST_FLIP) {
-          c->nflag[q] = c->ch_lf[l];
+          A.nflag[q] = c->ch_lf[l];
           continue;
         }
         const int p = c->ch_p[l];
         const int kv = c->bvar[p];
-        const double klb = c->blb[p], kub = c->bub[p];
+        const double klb = A.blb[p], kub = A.bub[p];
         c->bvar[p] = c->nvar[q];
-        c->blb[p] = c->nlb[q];
-        c->bub[p] = c->nub[q];
+        A.blb[p] = A.nlb[q];
+        A.bub[p] = A.nub[q];
         c->nvar[q] = kv;
-        c->nlb[q] = klb;
-        c->nub[q] = kub;
-        c->nflag[q] = c->ch_lf[l];
+        A.nlb[q] = klb;
+        A.nub[q] = kub;
+        A.nflag[q] = c->ch_lf[l];
       }
       const int piv_n = c->ch_cnt[nch - 1];
       c->it_cnt += piv_n;
@@ -2672,7 +2768,7 @@ __global__ __launch_bounds__(256) void k_fbc2(Ctl *c) {
       c->n_bulk++;
       if (c->budget > 0) c->budget -= piv_n;
       c->stall = c->ch_stall[nch - 1];
-      c->curA += nch;
+      c->curA = 0; // the current weights are in set 0
       c->pc_n = 0;
       c->pc_epoch++;
       c->pc_arrive = 0;
@@ -3534,11 +3630,11 @@ void launch_fbc(Ctl *d_ctl, int m, int n, hipStream_t s) {
 #undef FBC_CASE
   std::abort(); // unreachable: chain_supported() gates the call
 }
-// speculative chained primal path: row groups of the candidate column phase (4 rows per lane up to 16 groups, then 16)
+// speculative chained primal path: row groups of the candidate column phase (2 rows per lane up to 16 groups, then 16)
 static void fcs_shape(int m, int *U, int *R) {
-  int r = (m + 1023) / 1024;
+  int r = (m + 511) / 512;
   if (r <= 16) {
-    *U = 4;
+    *U = 2;
     *R = r < 1 ? 1 : r;
   } else {
     *U = 16;
@@ -3550,21 +3646,22 @@ int fcs_row_groups(int m) {
   fcs_shape(m, &U, &R);
   return R;
 }
-void launch_fcs(Ctl *d_ctl, int m, int n, int g, int boot, hipStream_t s) {
+void launch_fcs(const FcsArgs &a, int g, int boot, hipStream_t s) {
   int U, R;
-  fcs_shape(m, &U, &R);
-  dim3 grid(fused_npb(n), R);
-  if (U == 4) hipLaunchKernelGGL((k_fcs<4, 4>), grid, dim3(256), 0, s, d_ctl, g, boot);
-  else hipLaunchKernelGGL((k_fcs<16, 1>), grid, dim3(256), 0, s, d_ctl, g, boot);
+  fcs_shape(a.m, &U, &R);
+  dim3 grid(a.ncb, R);
+  if (U == 2) hipLaunchKernelGGL((k_fcs<2>), grid, dim3(256), 0, s, a, g, boot);
+  else hipLaunchKernelGGL((k_fcs<16>), grid, dim3(256), 0, s, a, g, boot);
 }
-void launch_fbc2(Ctl *d_ctl, int m, int n, hipStream_t s) {
+void launch_fbc2(const FcsArgs &a, hipStream_t s) {
+  const int m = a.m, n = a.n;
   const int pairs = (n + 2) / 2;
   int tr = pick_tr(m, n);
   if (tr > 16) tr = 16;
   const int nt = pick_nt(m, n);
   dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
 #define FBC2_CASE(TR_, NT_) \
-  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fbc2<TR_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
+  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fbc2<TR_, NT_>), grid, dim3(256), 0, s, a); return; }
   FBC2_CASE(16, 0) FBC2_CASE(16, 1) FBC2_CASE(16, 2) FBC2_CASE(8, 0) FBC2_CASE(8, 1) FBC2_CASE(8, 2) FBC2_CASE(4, 0) FBC2_CASE(4, 1) FBC2_CASE(4, 2)
 #undef FBC2_CASE
   std::abort(); // unreachable

@@ -139,12 +139,32 @@ struct Ctl {
   Cand *spr[2];    // [ncb * R] ratio-test partials of the candidates, one per row group
   double *spcol[2]; // [ncb][m_cap+1] the candidate columns
   double *drow[2]; // [ld] objective row
+  double *betak[2]; // [m_cap+1] basic values as of the step (column 0 carried through the pending chain)
   int pc_n;        // steps recorded in the pending chain (k_fbc2 applies them and resets it)
   int pc_epoch;    // chains applied so far + 1
   unsigned pc_arrive; // k_fbc2: workgroups that have finished (the last one commits the chain's bookkeeping)
   int ch_kind[KCH], ch_cnt[KCH], ch_ok[KCH]; // ST_PIVOT / ST_FLIP; pivots among steps 0..l; == pc_epoch once step l is recorded
   double ch_delta[KCH]; // bound flips: the entering variable's move
   unsigned long long *dbg; // diagnostic phase stamps of k_fcs (MVX_FCS_DBG=1), nullptr otherwise
+};
+
+// What the kernels of the speculative chained primal path need that the host knows (pointers, geometry, tolerances):
+// passed by value, so that no dependent load stands between a launch and its data; what the device decides -- the
+// chain, the counters, the verdicts -- stays in the control block.
+struct FcsArgs {
+  Ctl *c;
+  double *T;
+  double *blb, *bub, *nlb, *nub;
+  int *nflag;
+  SpecPart *sp[2];
+  Cand *spr[2];
+  double *spcol[2], *drow[2], *pw[2], *betak[2];
+  double *srow0, *colq0; // scaled pivot rows / pivot columns of the chain's steps, `sstride` / `cstride` doubles apart
+  size_t sstride, cstride;
+  int m, n, ld, mcap1;
+  double tol_dj, tol_piv, tol_bnd, sgn;
+  int stall_limit;
+  int ncb, R; // column blocks / row groups of k_fcs's grid
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots

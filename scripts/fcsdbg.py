@@ -12,9 +12,9 @@ P.load_dense(A, b, c)
 P.simplex(it_lim=piv)
 lib = mvolps_amd.load_library()
 lib.mvx_fcs_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
-buf = (C.c_ulonglong * (33 * 8))()
+buf = (C.c_ulonglong * (34 * 8))()
 rows = lib.mvx_fcs_debug_stamps(buf)
-names = ["L1+winner", "L2 loads", "row carry", "stores/copy", "local best", "gather", "carry", "ratio/out"]
+names = ["entry", "to winner", "L2 loads", "row phase", "local best", "fresh col", "own step", "ratio/out"]
 print("pos  " + " ".join("%11s" % x for x in names) + "   total_us")
 for g in list(range(rows - 1)) + [rows - 1]:
     st = [buf[g * 8 + k] for k in range(8)]
@@ -22,3 +22,5 @@ for g in list(range(rows - 1)) + [rows - 1]:
         continue
     d = [(st[k + 1] - st[k]) / 100.0 if st[k + 1] and st[k] else 0.0 for k in range(7)]
     print("%-4s " % ("boot" if g == rows - 1 else g) + " ".join("%11.2f" % x for x in [0.0] + d) + "   %8.2f" % ((max(st) - st[0]) / 100.0))
+
+print("blocks: kept candidate %d, fresh column %d, no candidate %d" % (buf[33 * 8], buf[33 * 8 + 1], buf[33 * 8 + 2]))
