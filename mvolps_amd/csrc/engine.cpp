@@ -47,15 +47,12 @@ namespace mvx {
 void set_tuning(int tr, int hot, int nt);
 int fused_npb(int n);
 int fused_nrb_max(int m);
-void launch_fboot(Ctl *, int n, hipStream_t);
-void launch_fa(Ctl *, int n, hipStream_t, int probe = 0);
-void launch_fb(Ctl *, int m, int n, hipStream_t, int boot = 0);
-void launch_fc(Ctl *, int m, int n, int k, hipStream_t);
-bool chain_supported(int m, int n);
-void launch_fbc(Ctl *, int m, int n, hipStream_t);
-int fcs_row_groups(int m);
-void launch_fcs(const FcsArgs &, int g, int boot, hipStream_t);
-void launch_fbc2(const FcsArgs &, hipStream_t);
+int chain_ncb(int n);
+int chain_nrb(int m);
+void launch_pboot(const ChainArgs &, hipStream_t);
+void launch_pstep(const ChainArgs &, int g, hipStream_t);
+void launch_pc(const ChainArgs &, int g, hipStream_t);
+void launch_fbc2(const ChainArgs &, hipStream_t);
 void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
@@ -102,10 +99,11 @@ struct SolveCtx {
   int *d_tflag = nullptr;  // tableau refresh: target non-basic status by variable number
   double *d_pw[2] = {nullptr, nullptr}; // primal devex weights by column, two sets (fused path ping-pong)
   double *d_srowk[KCH] = {}, *d_colqk[KCH] = {}; // chained primal path: scaled pivot rows / pivot columns of the steps
-  // speculative chained path (k_fcs): candidates, their ratio-test partials and columns, the objective row -- two sets each
-  SpecPart *d_sp[2] = {nullptr, nullptr};
-  Cand *d_spr[2] = {nullptr, nullptr};
-  double *d_spcol[2] = {nullptr, nullptr}, *d_drow[2] = {nullptr, nullptr}, *d_betak[2] = {nullptr, nullptr};
+  // chained primal path: what a step changes besides the tableau, in two alternating sets (ChainArgs), and the partials
+  double *d_drowk[2] = {}, *d_pwk[2] = {}, *d_nlbk[2] = {}, *d_nubk[2] = {}, *d_betak[2] = {}, *d_blbk[2] = {}, *d_bubk[2] = {};
+  int *d_nflagk[2] = {};
+  double *d_betab = nullptr, *d_ppart = nullptr, *d_rpart = nullptr;
+  size_t pp_stride = 0, rp_stride = 0;
   size_t sk_stride = 0, ck_stride = 0; // doubles between the chain's consecutive scaled pivot rows / pivot columns
   Cand *d_rpc = nullptr;
   double *d_olb = nullptr, *d_oub = nullptr; // bounds by variable number, saved by the anti-stalling perturbation
@@ -284,15 +282,13 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   size_t o_rpc = carve((size_t)((mc + 255) / 256 + 1) * sizeof(Cand));
   for (int k = 0; k < KCH; k++) o_sk[k] = carve((size_t)l * 8);
   for (int k = 0; k < KCH; k++) o_ck[k] = carve((size_t)(mc + 1) * 8);
-  const size_t ncb = (size_t)fused_npb(l), nrg = (size_t)std::max(16, fcs_row_groups(mc)); // (the group count is not monotone in m)
-  size_t o_sp[2], o_spr[2], o_spcol[2], o_drow[2], o_betak[2];
+  size_t o_colset[2][5], o_rowset[2][3];
   for (int k = 0; k < 2; k++) {
-    o_betak[k] = carve((size_t)(mc + 1) * 8);
-    o_sp[k] = carve(ncb * sizeof(SpecPart));
-    o_spr[k] = carve(ncb * nrg * sizeof(Cand));
-    o_spcol[k] = carve(ncb * (size_t)(mc + 1) * 8);
-    o_drow[k] = carve((size_t)l * 8);
+    for (int f = 0; f < 5; f++) o_colset[k][f] = carve((size_t)l * 8);
+    for (int f = 0; f < 3; f++) o_rowset[k][f] = carve((size_t)(mc + 1) * 8);
   }
+  const size_t pps = align_up((size_t)chain_ncb(l) + 1, 32), rps = align_up((size_t)chain_nrb(mc) + 1, 32);
+  const size_t o_betab = carve((size_t)(mc + 1) * 8), o_ppart = carve(8 * pps * 8), o_rpart = carve(4 * rps * 8);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -324,12 +320,20 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
     sc.d_colqk[k] = (double *)(b + o_ck[k]);
   }
   for (int k = 0; k < 2; k++) {
-    sc.d_sp[k] = (SpecPart *)(b + o_sp[k]);
-    sc.d_spr[k] = (Cand *)(b + o_spr[k]);
-    sc.d_spcol[k] = (double *)(b + o_spcol[k]);
-    sc.d_drow[k] = (double *)(b + o_drow[k]);
-    sc.d_betak[k] = (double *)(b + o_betak[k]);
+    sc.d_drowk[k] = (double *)(b + o_colset[k][0]);
+    sc.d_pwk[k] = (double *)(b + o_colset[k][1]);
+    sc.d_nlbk[k] = (double *)(b + o_colset[k][2]);
+    sc.d_nubk[k] = (double *)(b + o_colset[k][3]);
+    sc.d_nflagk[k] = (int *)(b + o_colset[k][4]);
+    sc.d_betak[k] = (double *)(b + o_rowset[k][0]);
+    sc.d_blbk[k] = (double *)(b + o_rowset[k][1]);
+    sc.d_bubk[k] = (double *)(b + o_rowset[k][2]);
   }
+  sc.d_betab = (double *)(b + o_betab);
+  sc.d_ppart = (double *)(b + o_ppart);
+  sc.d_rpart = (double *)(b + o_rpart);
+  sc.pp_stride = pps;
+  sc.rp_stride = rps;
   sc.sk_stride = (o_sk[1] - o_sk[0]) / 8;
   sc.ck_stride = (o_ck[1] - o_ck[0]) / 8;
   sc.stage_bytes = stage_size(mc, l);
@@ -623,13 +627,6 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
     h->srowk[k] = sc.d_srowk[k];
     h->colqk[k] = sc.d_colqk[k];
   }
-  for (int k = 0; k < 2; k++) {
-    h->sp[k] = sc.d_sp[k];
-    h->spr[k] = sc.d_spr[k];
-    h->spcol[k] = sc.d_spcol[k];
-    h->drow[k] = sc.d_drow[k];
-    h->betak[k] = sc.d_betak[k];
-  }
   h->pc_epoch = 1;
   {
     static unsigned long long *dbg = nullptr;
@@ -637,8 +634,8 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
     if (!looked) {
       looked = true;
       if (std::getenv("MVX_FCS_DBG")) {
-        HIPCHECK(hipMalloc((void **)&dbg, (size_t)(KCH + 2) * 8 * 8));
-        HIPCHECK(hipMemset(dbg, 0, (size_t)(KCH + 2) * 8 * 8));
+        HIPCHECK(hipMalloc((void **)&dbg, (size_t)KCH * 16 * 8));
+        HIPCHECK(hipMemset(dbg, 0, (size_t)KCH * 16 * 8));
       }
     }
     h->dbg = dbg;
@@ -884,7 +881,7 @@ struct SolveJob {
   bool persist_queued = false; // this batch of launches contains a k_persist launch (its abort flag is copied back)
   int seen_steps = 0, seen_pivots = 0, seen_bulk = 0;
   int chain = 1, chain0 = 1; // pivots per bulk launch the next batch is queued for / the size rule's choice
-  FcsArgs fargs{};           // what the kernels of the speculative chained path take by value
+  ChainArgs cargs{};         // what the kernels of the chained primal path take by value
   size_t ev_used = 0;
   bool profiled = false;
   int rc = 0;
@@ -933,20 +930,23 @@ static void job_begin(Context &c, SolveJob &J) {
   upload_ctl(sc);
   HIPCHECK(hipEventRecord(sc.ev_a, sc.stream));
   {
-    FcsArgs &a = J.fargs;
+    ChainArgs &a = J.cargs;
     a.c = sc.d_ctl;
     a.T = P->d_T;
     a.blb = P->d_blb; a.bub = P->d_bub; a.nlb = P->d_nlb; a.nub = P->d_nub; a.nflag = P->d_nflag;
+    a.betab = sc.d_betab;
     for (int k = 0; k < 2; k++) {
-      a.sp[k] = sc.d_sp[k]; a.spr[k] = sc.d_spr[k]; a.spcol[k] = sc.d_spcol[k];
-      a.drow[k] = sc.d_drow[k]; a.pw[k] = sc.d_pw[k]; a.betak[k] = sc.d_betak[k];
+      a.pw[k] = sc.d_pw[k];
+      a.drowk[k] = sc.d_drowk[k]; a.pwk[k] = sc.d_pwk[k]; a.nlbk[k] = sc.d_nlbk[k]; a.nubk[k] = sc.d_nubk[k]; a.nflagk[k] = sc.d_nflagk[k];
+      a.betak[k] = sc.d_betak[k]; a.blbk[k] = sc.d_blbk[k]; a.bubk[k] = sc.d_bubk[k];
     }
+    a.pp = sc.d_ppart; a.rp = sc.d_rpart; a.ppstride = sc.pp_stride; a.rpstride = sc.rp_stride;
     a.srow0 = sc.d_srowk[0]; a.colq0 = sc.d_colqk[0];
     a.sstride = sc.sk_stride; a.cstride = sc.ck_stride;
     a.m = P->m; a.n = P->n; a.ld = P->ld; a.mcap1 = P->m_cap + 1;
+    a.ncb = chain_ncb(P->n); a.nrb = chain_nrb(P->m);
     a.tol_dj = h->tol_dj; a.tol_piv = h->tol_piv; a.tol_bnd = h->tol_bnd; a.sgn = h->sgn;
     a.stall_limit = h->stall_limit;
-    a.ncb = fused_npb(P->n); a.R = fcs_row_groups(P->m);
   }
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   J.chain = J.chain0 = h->chain_max;
@@ -1034,22 +1034,21 @@ static void job_enqueue(Context &c, SolveJob &J) {
         const size_t e_generic = J.ev_used;
         if (J.profiled) J.ev_used += 2;
         if (depth > 0) {
-          // speculative chained path: one k_fcs launch per step (the first one of a call only leaves the candidates),
-          // one bulk launch k_fbc2 per chain of up to `kc` steps, so `depth` pivots take depth / kc passes over the
-          // tableau when every chain fills (a chain that ends early leaves pivots for the next batch)
-          J.fargs.m = m_grid;
-          launch_fcs(J.fargs, 0, 1, sc.stream);
+          // chained path: k_pboot once, then per chain of up to `kc` steps two small launches per step (k_pc / k_pr)
+          // and one bulk launch (k_fbc2), so `depth` pivots take depth / kc passes over the tableau when every chain
+          // fills (a chain that ends early leaves pivots for the next batch)
+          launch_pboot(J.cargs, sc.stream);
           const int kc = std::max(1, J.chain);
           for (int left = depth; left > 0;) {
             const int steps = std::min(kc, left); // the last pass of a limited run chains only what the limit leaves
-            for (int t = 0; t < steps; t++) launch_fcs(J.fargs, t, 0, sc.stream);
+            for (int t = 0; t < steps; t++) launch_pstep(J.cargs, t, sc.stream);
             ev();
-            launch_fbc2(J.fargs, sc.stream);
+            launch_fbc2(J.cargs, sc.stream);
             ev();
             left -= steps;
           }
-          // a run that may end on the pivot limit: one more step launch, which finds the limit and reports it
-          if (J.parm.it_lim >= 0 && depth >= remaining) launch_fcs(J.fargs, 0, 0, sc.stream);
+          // a run that may end on the pivot limit: one more column phase, which finds the limit and reports it
+          if (J.parm.it_lim >= 0 && depth >= remaining) launch_pc(J.cargs, 0, sc.stream);
         }
         launch_select(sc.d_ctl, sc.stream);
         if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic], sc.stream));
@@ -2200,8 +2199,8 @@ int fcs_debug_stamps(unsigned long long *out) {
   Context &c = ctx();
   if (!c.main.h_ctl || !c.main.h_ctl->dbg) return 0;
   HIPCHECK(hipDeviceSynchronize());
-  HIPCHECK(hipMemcpy(out, c.main.h_ctl->dbg, (size_t)(KCH + 2) * 8 * 8, hipMemcpyDeviceToHost));
-  return KCH + 1;
+  HIPCHECK(hipMemcpy(out, c.main.h_ctl->dbg, (size_t)KCH * 16 * 8, hipMemcpyDeviceToHost));
+  return KCH;
 }
 void set_stall_limit(int limit) { g_stall_limit = limit > 0 ? limit : 0; }
 void set_batch_slots(int k) { g_batch_slots = k < 2 ? 2 : (k > 256 ? 256 : k); }

@@ -1363,69 +1363,6 @@ __device__ __forceinline__ bool price_col(int f, double dj, double tol, int j, d
   return true;
 }
 
-// bootstrap: price the current objective row into pp[curA]; arm the fused path.
-// A call that has just begun (phase PH_START, no bound edits waiting) is taken from its first pivot: every block repeats
-// select_step's opening check -- no basic variable outside its bounds by more than the tolerance -- and, if that holds,
-// the primal devex weights restart from one exactly as the generic step's `fresh_primal` does.  The phase itself is
-// written by the bootstrap k_fb (its lead lane), after every block of this kernel has read it.
-__global__ __launch_bounds__(256) void k_fboot(Ctl *c) {
-  __shared__ Cand lds[17];
-  const int phase = c->phase;
-  const bool fresh = (phase == PH_START);
-  if (c->done != D_RUN || c->stall >= c->stall_limit || !(phase == PH_PRIMAL2 || (fresh && c->n_edits == 0))) { // no Bland pricing here
-    if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
-    return;
-  }
-  if (fresh) {
-    const int m = c->m;
-    const size_t ld = (size_t)c->ld;
-    const double tol = c->tol_bnd;
-    const double *T = c->T, *blb = c->blb, *bub = c->bub;
-    int bad = 0;
-    for (int i0 = 1 + TIDX; i0 <= m; i0 += 256 * 8) { // eight strided loads in flight per lane
-      double beta[8], lb[8], ub[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = i0 + 256 * u;
-        const bool in = (i <= m);
-        beta[u] = in ? T[(size_t)i * ld] : 0.0;
-        lb[u] = in ? blb[i] : -INFINITY;
-        ub[u] = in ? bub[i] : INFINITY;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        if (lb[u] > -INFINITY && beta[u] < lb[u] - tol * (1.0 + fabs(lb[u]))) bad = 1;
-        if (ub[u] < INFINITY && beta[u] > ub[u] + tol * (1.0 + fabs(ub[u]))) bad = 1;
-      }
-    }
-    if (__syncthreads_or(bad)) { // not primal feasible: the generic step decides between the dual simplex and phase 1
-      if (blockIdx.x == 0 && TIDX == 0) c->fstate = F_OFF;
-      return;
-    }
-  }
-  // The ping-pong parity stays where the last fused run left it (curA): the current devex weights live in
-  // pw[curA].  The bootstrap k_fb reads side curB = curA^1 and flips curA back to where it is now.
-  const int a = c->curA & 1;
-  const int j = (int)blockIdx.x * 256 + TIDX;
-  Cand best{0.0, 0.0, 0, 0};
-  if (j <= c->n) {
-    double w = 1.0;
-    if (fresh) c->pw[a][j] = 1.0;
-    else w = c->pw[a][j];
-    if (j >= 1) {
-      Cand x{0.0, 0.0, 0, 0};
-      if (price_col(c->nflag[j], c->sgn * c->T[j], c->tol_dj, j, w, x)) best = x;
-    }
-  }
-  best = block_best<0>(best, lds);
-  if (TIDX == 0) c->pp[a][blockIdx.x] = best;
-  if (blockIdx.x == 0 && TIDX == 0) {
-    c->fstate = F_RUN;
-    c->step = ST_NONE;
-    c->curB = a ^ 1;
-  }
-}
-
 // wave-level arg-best over values already in registers, broadcast to all lanes
 template <int MODE>
 __device__ __forceinline__ Cand wave_bcast_best(Cand b) {
@@ -1436,169 +1373,6 @@ __device__ __forceinline__ Cand wave_bcast_best(Cand b) {
   r.idx = __shfl(b.idx, 0, 64);
   r.aux = __shfl(b.aux, 0, 64);
   return r;
-}
-
-// Three dependent memory levels only: (1) the control block, (2) partials + this lane's own
-// objective-row entry, (3) what depends on the chosen q / p.  Loads of one level are issued
-// together, before the first use.
-__global__ __launch_bounds__(256) void k_fa(Ctl *c, int probe) {
-  __shared__ Cand lds[17];
-  // level 1
-  const int done = c->done, fstate = c->fstate, cur = c->curA, budget = c->budget;
-  const int stall = c->stall, stall_limit = c->stall_limit;
-  const int npb = c->npb, nrb = c->nrb, n = c->n, ldi = c->ld;
-  double *const T = c->T;
-  double *const srow = c->srow;
-  const int *const nflag = c->nflag;
-  const double *const nlb = c->nlb, *const nub = c->nub, *const blb = c->blb, *const bub = c->bub;
-  const double *const colq = c->colqx[cur];
-  const Cand *const pp = c->pp[cur];
-  Cand *const ppn = c->pp[cur ^ 1];
-  const Cand *const rp = c->rp;
-  const double *const pwc = c->pw[cur & 1];
-  double *const pwn = c->pw[(cur & 1) ^ 1];
-  const double tol = c->tol_dj, sgn = c->sgn;
-  if (done != D_RUN || fstate != F_RUN) return;
-  const bool lead = (blockIdx.x == 0 && TIDX == 0);
-  const int lane = TIDX & 63;
-  const int j = (int)blockIdx.x * 256 + TIDX;
-  const bool act = (j <= n);
-  // level 2
-  Cand pc = (lane < npb) ? pp[lane] : Cand{0.0, 0.0, 0, 0};
-  Cand rc{0.0, 0.0, 0, 0};
-  {
-    Cand r0 = (lane < nrb) ? rp[lane] : Cand{0.0, 0.0, 0, 0};
-    Cand r1 = (lane + 64 < nrb) ? rp[lane + 64] : Cand{0.0, 0.0, 0, 0};
-    Cand r2 = (lane + 128 < nrb) ? rp[lane + 128] : Cand{0.0, 0.0, 0, 0};
-    Cand r3 = (lane + 192 < nrb) ? rp[lane + 192] : Cand{0.0, 0.0, 0, 0};
-    const double dold_ = act ? T[j] : 0.0;
-    const int fj_ = (act && j >= 1) ? nflag[j] : MVX_NS;
-    const double wj_ = (act && j >= 1) ? pwc[j] : 1.0; // primal devex weight of this lane's column
-    for (int k = lane + 64; k < npb; k += 64) {
-      Cand x = pp[k];
-      if (cand_better<0>(x, pc)) pc = x;
-    }
-    rc = r0;
-    if (cand_better<1>(r1, rc)) rc = r1;
-    if (cand_better<1>(r2, rc)) rc = r2;
-    if (cand_better<1>(r3, rc)) rc = r3;
-    for (int k = lane + 256; k < nrb; k += 64) {
-      Cand x = rp[k];
-      if (cand_better<1>(x, rc)) rc = x;
-    }
-    pc = wave_bcast_best<0>(pc);
-    rc = wave_bcast_best<1>(rc);
-    // entering column (none, no budget, or a stalled run that Bland's rule must take over: the generic
-    // path continues)
-    if (pc.idx == 0 || budget == 0 || stall >= stall_limit) {
-      if (lead) {
-        c->fstate = F_STOP;
-        // The pivot limit with an entering column still on offer and nothing perturbed is what the generic step would
-        // report as it stands (select_step: price, then `budget == 0` -> D_ITLIM); saying so here saves the solve a
-        // host round trip whose only purpose is that one selection.
-        if (pc.idx != 0 && budget == 0 && stall < stall_limit && !c->perturbed) {
-          c->done = D_ITLIM;
-          c->step = ST_NONE;
-        }
-      }
-      return;
-    }
-    if (probe) return; // last launch of a queued run: only there to notice the pivot limit, prepares nothing
-    const int q = pc.idx, sdir = pc.aux;
-    const int p = rc.idx, p_up = rc.aux; // p == 0: no blocking row
-    // level 3
-    const double lbq = nlb[q], ubq = nub[q];
-    const int fq = nflag[q];
-    const int pr = p ? p : 1;
-    const double piv = colq[pr], dq = colq[0];
-    const double wq = pwc[q];
-    const double plb = blb[pr], pub = bub[pr];
-    const double v = act ? T[(size_t)pr * ldi + j] : 0.0;
-    Cand best{0.0, 0.0, 0, 0};
-    if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
-      const double tf = ubq - lbq;
-      if (p == 0 || tf <= rc.k1) {
-        // bound flip: tableau body and objective row unchanged; column q changes status
-        const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
-        if (act && j >= 1) {
-          Cand x{0.0, 0.0, 0, 0};
-          pwn[j] = wj_; // weights unchanged by a flip; the other set becomes current with k_fb's curA flip
-          if (price_col(j == q ? nf : fj_, sgn * dold_, tol, j, wj_, x)) best = x;
-        }
-        best = block_best<0>(best, lds);
-        if (TIDX == 0) ppn[blockIdx.x] = best;
-        if (lead) {
-          c->step = ST_FLIP;
-          c->q = q;
-          c->sdir = sdir;
-          c->delta = (sdir > 0) ? tf : -tf;
-          c->flipflag = nf;
-          c->curB = cur;
-          c->stall_new = 0;
-          c->nch = 1;
-          c->ch_alive = 0;
-        }
-        return;
-      }
-    }
-    if (p == 0) {
-      if (lead) c->fstate = F_STOP; // unbounded ray: the generic path reports it
-      return;
-    }
-    const double bound = p_up ? pub : plb;
-    const int lf = dev_leave_flag(plb, pub, p_up);
-    if (act) {
-      const double sj = (j == 0) ? xdiv(v - bound, piv) : xdiv(v, piv);
-      srow[j] = sj;
-      const double dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dold_);
-      T[j] = dnew;
-      if (j >= 1) {
-        // devex weight update from the scaled pivot row (oracle: primal_step), then the next pricing
-        double wn;
-        if (j == q) {
-          const double cc = xdiv(wq, piv * piv);
-          wn = cc > 1.0 ? cc : 1.0;
-        } else {
-          const double cc = sj * sj * wq;
-          wn = cc > wj_ ? cc : wj_;
-        }
-        pwn[j] = wn;
-        Cand x{0.0, 0.0, 0, 0};
-        if (price_col(j == q ? lf : fj_, sgn * dnew, tol, j, wn, x)) best = x;
-      }
-    }
-    best = block_best<0>(best, lds);
-    if (TIDX == 0) ppn[blockIdx.x] = best;
-    if (lead) {
-      c->step = ST_PIVOT;
-      c->p = p;
-      c->q = q;
-      c->sdir = sdir;
-      c->p_up = p_up;
-      c->piv = piv;
-      c->bound = bound;
-      c->xq = dev_nb_value(fq, lbq, ubq);
-      c->leave_flag = lf;
-      c->ent_lb = lbq;
-      c->ent_ub = ubq;
-      c->curB = cur;
-      c->stall_new = (rc.k1 <= DEGEN_TOL) ? stall + 1 : 0;
-      // step 0 of a chain (k_fcc / k_fcr may append to it before the bulk launch)
-      c->nch = 1;
-      c->ch_alive = (c->chain_max > 1) ? 1 : 0;
-      c->ch_p[0] = p;
-      c->ch_q[0] = q;
-      c->ch_lf[0] = lf;
-      c->ch_piv[0] = piv;
-      c->ch_xq[0] = dev_nb_value(fq, lbq, ubq);
-      c->ch_elb[0] = lbq;
-      c->ch_eub[0] = ubq;
-      c->ch_llb[0] = plb;
-      c->ch_lub[0] = pub;
-      c->ch_s0[0] = xdiv(v - bound, piv); // lane 0 of block 0 owns column 0: v = T[p][0]
-      c->ch_stall[0] = (rc.k1 <= DEGEN_TOL) ? stall + 1 : 0;
-    }
-  }
 }
 
 // Row block rb covers rows 1 + rb*TR .. (rb+1)*TR; row 0 (objective) belongs to k_fa.  The slab
@@ -1786,376 +1560,30 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 }
 
 // ================================================================= chained primal path
-// One pass over the tableau for up to KCH pivots.  After k_fa has prepared step 0 of a chain, k_fcc / k_fcr (two small
-// launches per step) choose the following steps without the bulk update having run: everything the selection of step k reads -- the
-// entering column q_k, the basic values, the leaving row p_k -- is an O(m + n) slice of the tableau as it stands in
-// memory, carried through steps 0..k-1 entry by entry with exactly the operations the bulk update would apply
-// (`chain_apply`, the per-entry case analysis of k_fb: pivot row, pivot column, fma elsewhere).  Row 0 and the devex
-// weights are updated in place step after step, as k_fa does for step 0.  k_fbc then streams the tableau ONCE and
-// applies all the steps to every entry in registers.  Same pivots, same bits as one launch per pivot -- the traffic per
-// pivot is what changes.  A chain ends early (the remaining work is then the ordinary path's) on: pivot limit, stall
-// limit, no entering column, a bound flip, an unbounded ray.
-// Step k >= 1 of a chain takes two small multi-workgroup launches, the counterparts of what k_fb's column export and
-// k_fa do for step 0:
-//   k_fcc (one lane per row): entering column q_k = reduction of the pricing partials; column q_k and the basic values as
-//          of step k; ratio-test partial per block; the lead lane stashes what k_fcr's lanes would otherwise read from
-//          entries their neighbours overwrite (d_q, the weight of q);
-//   k_fcr (one lane per column, k_fa's shape): leaving row p_k = reduction of those partials; row p_k as of step k ->
-//          scaled pivot row, objective row and devex weights in place, pricing partials for step k+1; the lead lane
-//          appends the step to the chain.
-// Every block of a kernel reaches the same verdict on whether the chain goes on (the reduction keys are a total order),
-// and only the lead lane writes it down -- for the NEXT kernel; a block that starts late and finds the chain already
-// closed returns, as it would have decided itself.
-__global__ __launch_bounds__(256) void k_fcc(Ctl *c, int k) {
-  __shared__ Cand lds[17];
-  __shared__ ChainView v;
-  const ChainRec rec = chain_fetch(c, k); // same load level as the fields below
-  if (c->done != D_RUN || c->fstate != F_RUN || !c->ch_alive) return;
-  const bool lead = (blockIdx.x == 0 && TIDX == 0);
-  const int cur = c->curB, nxt = cur ^ 1;
-  const int m = c->m, npb = c->npb, budget = c->budget, stall_limit = c->stall_limit;
-  const size_t ld = (size_t)c->ld;
-  const double *const T = c->T;
-  const Cand *const pp = c->pp[nxt];
-  const int stall = c->ch_stall[k - 1];
-  // entering column: reduction of the pricing partials the previous step left
-  Cand pc{0.0, 0.0, 0, 0};
-  for (int t = TIDX & 63; t < npb; t += 64) {
-    Cand x = pp[t];
-    if (cand_better<0>(x, pc)) pc = x;
-  }
-  pc = wave_bcast_best<0>(pc);
-  if (pc.idx == 0 || (budget >= 0 && budget < k + 1) || stall >= stall_limit) {
-    if (lead) c->ch_alive = 0;
-    return;
-  }
-  const int q = pc.idx, sdir = pc.aux;
-  // this lane's row of the tableau as it stands: requested before the barriers below, used after them
-  const int i = 1 + (int)blockIdx.x * 256 + TIDX;
-  double a = 0.0, beta = 0.0, lb = 0.0, ub = 0.0;
-  if (i <= m) {
-    a = T[(size_t)i * ld + q];
-    beta = c->betac[cur][i];
-    lb = c->blb[i];
-    ub = c->bub[i];
-  }
-  __shared__ double s_sq[KCH]; // scaled pivot row entries of column q, steps 0..k-1: one load each instead of one per lane
-  if (TIDX < k) s_sq[TIDX] = rec.sr[q];
-  chain_store(rec, k, v); // (ends with the barrier that also publishes s_sq)
-  double *const ck = c->colqk[k];
-  Cand rb{0.0, 0.0, 0, 0};
-  if (i <= m) {
-    for (int l = 0; l < k; l++) {
-      const double ci = v.cq[l][i];
-      a = chain_apply(v.st[l], i, q, a, ci, s_sq[l]);
-      beta = chain_apply(v.st[l], i, 0, beta, ci, v.st[l].s0);
-      if (v.st[l].p == i) {
-        lb = v.elb[l];
-        ub = v.eub[l];
-      }
-    }
-    ck[i] = a;
-    Cand x{0.0, 0.0, 0, 0};
-    if (ratio_row(a, sdir, beta, lb, ub, 0, c->tol_piv, i, x)) rb = x;
-  }
-  rb = block_best<1>(rb, lds);
-  if (TIDX == 0) c->rpc[blockIdx.x] = rb;
-  if (lead) {
-    // the entering variable as the earlier steps of the chain left it (bounds, status)
-    double lbq = c->nlb[q], ubq = c->nub[q];
-    int fq = c->nflag[q];
-    for (int l = 0; l < k; l++) {
-      if (v.st[l].q == q) {
-        lbq = v.llb[l];
-        ubq = v.lub[l];
-        fq = v.st[l].lf;
-      }
-    }
-    const double dq = T[q];
-    ck[0] = dq;
-    c->ch_q[k] = q;
-    c->ch_sdir[k] = sdir;
-    c->ch_elb[k] = lbq;
-    c->ch_eub[k] = ubq;
-    c->ch_fq[k] = fq;
-    c->ch_dq[k] = dq;
-    c->ch_wq[k] = c->pw[nxt][q];
-    c->ch_nrpc = (int)gridDim.x;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_fcr(Ctl *c, int k) {
-  __shared__ Cand lds[17];
-  __shared__ ChainView v;
-  const ChainRec rec = chain_fetch(c, k); // same load level as the fields below
-  if (c->done != D_RUN || c->fstate != F_RUN || !c->ch_alive) return;
-  const bool lead = (blockIdx.x == 0 && TIDX == 0);
-  const int cur = c->curB, nxt = cur ^ 1;
-  const int n = c->n, nrpc = c->ch_nrpc;
-  const size_t ld = (size_t)c->ld;
-  double *const T = c->T;
-  const int q = c->ch_q[k];
-  const double lbq = c->ch_elb[k], ubq = c->ch_eub[k], dq = c->ch_dq[k], wq = c->ch_wq[k];
-  const int fq = c->ch_fq[k];
-  // leaving row: reduction of the ratio-test partials
-  Cand rc{0.0, 0.0, 0, 0};
-  for (int t = TIDX & 63; t < nrpc; t += 64) {
-    Cand x = c->rpc[t];
-    if (cand_better<1>(x, rc)) rc = x;
-  }
-  rc = wave_bcast_best<1>(rc);
-  bool stop = (rc.idx == 0); // unbounded ray: the generic path reports it
-  if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
-    const double tf = ubq - lbq;
-    if (rc.idx == 0 || tf <= rc.k1) stop = true; // bound flip: the ordinary path takes it
-  }
-  if (stop) {
-    if (lead) c->ch_alive = 0;
-    return;
-  }
-  const int p = rc.idx, p_up = rc.aux;
-  // what this lane needs of the tableau as it stands and of the leaving row's record: requested before the barrier
-  const int j = (int)blockIdx.x * 256 + TIDX;
-  const double val0 = (j <= n) ? T[(size_t)p * ld + j] : 0.0;
-  const double dold0 = (j <= n) ? T[j] : 0.0;
-  const double piv = c->colqk[k][p];
-  __shared__ double s_cp[KCH]; // pivot column entries of row p, steps 0..k-1: one load each instead of one per lane
-  if (TIDX < k) s_cp[TIDX] = rec.cq[p];
-  chain_store(rec, k, v); // (ends with the barrier that also publishes s_cp)
-  double plb = c->blb[p], pub = c->bub[p];
-  for (int l = 0; l < k; l++)
-    if (v.st[l].p == p) {
-      plb = v.elb[l];
-      pub = v.eub[l];
-    }
-  const double bound = p_up ? pub : plb;
-  const int lf = dev_leave_flag(plb, pub, p_up);
-  double *const pw = c->pw[nxt];
-  double *const sk = c->srowk[k];
-  Cand best{0.0, 0.0, 0, 0};
-  double s0 = 0.0;
-  if (j <= n) {
-    double val = val0;
-    for (int l = 0; l < k; l++) val = chain_apply(v.st[l], p, j, val, s_cp[l], v.sr[l][j]);
-    const double sj = (j == 0) ? xdiv(val - bound, piv) : xdiv(val, piv);
-    sk[j] = sj;
-    s0 = sj;
-    const double dold = dold0;
-    const double dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dold);
-    T[j] = dnew;
-    if (j >= 1) {
-      double wn;
-      if (j == q) {
-        const double cc = xdiv(wq, piv * piv);
-        wn = cc > 1.0 ? cc : 1.0;
-      } else {
-        const double cc = sj * sj * wq;
-        const double wj = pw[j];
-        wn = cc > wj ? cc : wj;
-      }
-      pw[j] = wn;
-      int f = c->nflag[j];
-      for (int l = 0; l < k; l++)
-        if (v.st[l].q == j) f = v.st[l].lf;
-      if (j == q) f = lf;
-      Cand x{0.0, 0.0, 0, 0};
-      if (price_col(f, c->sgn * dnew, c->tol_dj, j, wn, x)) best = x;
-    }
-  }
-  best = block_best<0>(best, lds);
-  if (TIDX == 0) c->pp[nxt][blockIdx.x] = best; // k_fcc of this step has consumed the partials that were here
-  if (lead) {
-    c->ch_p[k] = p;
-    c->ch_pup[k] = p_up;
-    c->ch_lf[k] = lf;
-    c->ch_piv[k] = piv;
-    c->ch_bound[k] = bound;
-    c->ch_xq[k] = dev_nb_value(fq, lbq, ubq);
-    c->ch_llb[k] = plb;
-    c->ch_lub[k] = pub;
-    c->ch_s0[k] = s0; // lane 0 of block 0 owns column 0
-    c->ch_stall[k] = (rc.k1 <= DEGEN_TOL) ? c->ch_stall[k - 1] + 1 : 0;
-    c->nch = k + 1;
-  }
-}
-
-// The bulk launch of a chain: k_fb's stream with `nch` steps applied to every entry (nch == 1: exactly k_fb).  Flips
-// and the bootstrap never chain, so they stay with k_fb; this kernel sees ST_PIVOT only.
-template <int TR, int NT>
-__global__ __launch_bounds__(256) void k_fbc(Ctl *c) {
-  if (c->done != D_RUN || c->fstate != F_RUN) return;
-  const int nch = c->nch;
-  if (nch <= 1) { // a single pivot, a bound flip, the bootstrap: k_fb's own code
-    fb_body<TR, 1, NT, 0>(c);
-    return;
-  }
-  __shared__ ChainView cv;
-  const int cur = c->curB, nxt = cur ^ 1;
-  const int m = c->m, n = c->n;
-  const size_t ld = (size_t)c->ld;
-  const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
-  const bool active = (j0 <= n);
-  const int i0 = 1 + (int)blockIdx.y * TR;
-  const bool has0 = (j0 == 0);
-  double *bnew = c->betac[nxt];
-  const int npb = c->npb;
-  const Cand *ppn = c->pp[nxt];
-  Cand ncv = ((TIDX & 63) < npb) ? ppn[TIDX & 63] : Cand{0.0, 0.0, 0, 0};
-  chain_load(c, nch, cv);
-  __shared__ double s_ci[KCH][TR];
-  if (TIDX < nch * TR) s_ci[TIDX / TR][TIDX % TR] = cv.cq[TIDX / TR][i0 + TIDX % TR];
-  __syncthreads();
-  if (active) {
-    double *base = c->T + (size_t)i0 * ld + j0;
-    double2 v[TR];
-#pragma unroll
-    for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
-    // the pivot-column entries of the tile for every step sit in LDS (one load per lane up front instead of TR vector
-    // loads per lane and step); step l+1's pivot-row pair is requested while step l is applied
-    double2 s_n = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[0]) + j0);
-    for (int l = 0; l < nch; l++) {
-      const ChainStep st = cv.st[l];
-      const double2 s = s_n;
-      double ci[TR];
-#pragma unroll
-      for (int r = 0; r < TR; r++) ci[r] = s_ci[l][r];
-      if (l + 1 < nch) s_n = *reinterpret_cast<const double2 *>(uniform_ptr(cv.sr[l + 1]) + j0);
-      const bool q0 = (j0 == st.q), q1 = (j0 + 1 == st.q);
-#pragma unroll
-      for (int r = 0; r < TR; r++) {
-        v[r].x = fma(-ci[r], s.x, v[r].x);
-        v[r].y = fma(-ci[r], s.y, v[r].y);
-      }
-      if (q0 || q1) {
-#pragma unroll
-        for (int r = 0; r < TR; r++) {
-          const double qv = xdiv(ci[r], st.piv);
-          if (q0) v[r].x = qv;
-          if (q1) v[r].y = qv;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (st.p >= i0 && st.p < i0 + TR) {
-#pragma unroll
-        for (int r = 0; r < TR; r++) {
-          if (i0 + r == st.p) {
-            v[r].x = q0 ? xdiv(1.0, st.piv) : -s.x;
-            v[r].y = q1 ? xdiv(1.0, st.piv) : -s.y;
-            if (has0) v[r].x = st.xq - s.x;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
-    if (has0) {
-#pragma unroll
-      for (int r = 0; r < TR; r++) bnew[i0 + r] = v[r].x;
-    }
-  }
-  // next entering column (0 = none: k_fa will stop)
-  for (int k = (TIDX & 63) + 64; k < npb; k += 64) {
-    Cand x = ppn[k];
-    if (cand_better<0>(x, ncv)) ncv = x;
-  }
-  const Cand nc = wave_bcast_best<0>(ncv);
-  const int qn = nc.idx, sdn = nc.aux;
-  const bool tilen = (qn != 0 && (qn >> 9) == (int)blockIdx.x);
-  if (tilen) {
-    if (NT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores above are inline asm
-    __syncthreads();
-    if (TIDX < 64) {
-      Cand best{0.0, 0.0, 0, 0};
-      const double *b0 = c->betac[cur];
-      for (int r = TIDX; r < TR; r += 64) {
-        const int i = i0 + r;
-        if (i > m) break;
-        const double a = c->T[(size_t)i * ld + qn];
-        c->colqx[nxt][i] = a;
-        double beta = b0[i], lb = c->blb[i], ub = c->bub[i];
-        for (int l = 0; l < nch; l++) {
-          beta = chain_apply(cv.st[l], i, 0, beta, cv.cq[l][i], cv.st[l].s0);
-          if (cv.st[l].p == i) {
-            lb = cv.elb[l];
-            ub = cv.eub[l];
-          }
-        }
-        Cand x{0.0, 0.0, 0, 0};
-        if (ratio_row(a, sdn, beta, lb, ub, 0, c->tol_piv, i, x)) {
-          if (cand_better<1>(x, best)) best = x;
-        }
-      }
-      best = wave_best<1>(best);
-      if (TIDX == 0) c->rp[blockIdx.y] = best;
-    }
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && TIDX == 0) {
-    bnew[0] = c->T[0];
-    if (qn != 0) c->colqx[nxt][0] = c->T[qn];
-    for (int l = 0; l < nch; l++) { // the basis swaps of the chain, in order
-      const int p = cv.st[l].p, q = cv.st[l].q;
-      const int kv = c->bvar[p];
-      const double klb = c->blb[p], kub = c->bub[p];
-      c->bvar[p] = c->nvar[q];
-      c->blb[p] = c->nlb[q];
-      c->bub[p] = c->nub[q];
-      c->nvar[q] = kv;
-      c->nlb[q] = klb;
-      c->nub[q] = kub;
-      c->nflag[q] = cv.st[l].lf;
-    }
-    c->it_cnt += nch;
-    c->n_bulk++;
-    if (c->budget > 0) c->budget -= nch;
-    c->stall = c->ch_stall[nch - 1];
-    c->curA = nxt;
-    c->nrb = (int)gridDim.y;
-  }
-}
-
-// ================================================= speculative chained primal path (k_fcs / k_fbc2)
-// ONE launch per step of a chain.  The two launches per step of the path above exist because a pivot has two grid-wide
-// decisions -- the entering column (over n) and, once that column is known, the leaving row (over m).  Here every
-// column block answers the second question before the first has been asked: after it has carried its columns through
-// the step this launch prepares (objective row, devex weights, statuses), it prices them, takes ITS best column,
-// gathers that column from the tableau as it stands, carries it through the pending chain and runs the ratio test on it
-// -- a complete candidate pivot per block.  The next launch only has to reduce the candidates: the best score wins, and
-// its leaving row, pivot element and column come with it.  Same pivots, same bits as every other path (the reduction
-// keys are total orders; every entry goes through the same operations in the same order).
-//   k_fcs(g)   step g of the pending chain: winner of the candidates left by the previous launch -> row phase (scaled
-//              pivot row, objective row, weights) -> candidates for step g+1.  Grid: column blocks x row groups; a row
-//              group repeats the row phase of its column block and does its share of the rows of the candidate column.
-//              boot = 1: no step, only the candidates (start of a call; the tableau has no chain pending).
-//   k_fbc2     the bulk pass: every entry read and written once for the whole chain; the pivot-column entries of a tile
-//              are wave-uniform and come in through scalar loads, so the kernel needs no LDS and no barrier.
-// Bound flips are steps of the chain (only column 0 and the status of the flipped column change).  A chain ends early
-// on: no candidate, the pivot limit, the stall limit (Bland's rule and the perturbation stay with the generic step), an
-// unbounded ray.
-struct PStep {
-  int kind, p, q, lf;
-  double piv, xq, s0, delta;
-};
-// entry (i, j) with value v before step st -> after it; ci = entry of row i in the step's pivot column, sj = entry of
-// column j in its scaled pivot row
-__device__ __forceinline__ double papply(const PStep &st, int i, int j, double v, double ci, double sj) {
-  if (st.kind == ST_FLIP) return (j == 0) ? fma(ci, st.delta, v) : v;
-  if (i == st.p) return (j == st.q) ? xdiv(1.0, st.piv) : ((j == 0) ? st.xq - sj : -sj);
-  if (j == st.q) return xdiv(ci, st.piv);
-  return fma(-ci, sj, v);
-}
-struct PView { // the pending chain as every lane needs it (one copy per block, in LDS)
-  PStep st[KCH];
-  double elb[KCH], eub[KCH], llb[KCH], lub[KCH];
-  const double *cq[KCH];
-};
-
-// one earlier step of the chain applied to the leaving row's entry in column j (the divisions it would take are the
-// same for every lane and are done once per step: ip = 1 / piv, cd = cp / piv)
-__device__ __forceinline__ double prow(const PStep &st, int p, int j, double v, double cp, double t, double ip, double cd) {
-  if (st.kind == ST_FLIP) return (j == 0) ? fma(cp, st.delta, v) : v;
-  if (p == st.p) return (j == st.q) ? ip : ((j == 0) ? st.xq - t : -t);
-  return (j == st.q) ? cd : fma(-cp, t, v);
-}
+// Primal phase 2 of large tableaux.  The selection of a pivot reads O(m + n) entries of the tableau -- the objective
+// row, the entering column, the leaving row -- while the update touches all (m+1)(n+1).  So the pivots that follow one
+// another are chosen before any bulk update has run: column q_g and row p_g are read from the tableau as it stands in
+// memory and carried through steps 0..g-1 of the pending chain entry by entry, with exactly the operations the bulk
+// update would have applied; ONE bulk launch then streams the tableau once and applies the whole chain.  Same pivots,
+// same bits as one pass per pivot -- the traffic per pivot is the pass divided by the chain length.
+//   k_pboot      start of a call: is the basis primal feasible; devex weights; pricing partials of the objective row;
+//                column 0 exported contiguously
+//   k_pc(g)      column phase of step g (one lane per row): entering column q_g = reduction of the pricing partials;
+//                column q_g carried through the chain; ratio-test partial per block
+//   k_pr(g)      row phase of step g (one lane per column): leaving row p_g = reduction of those partials (or the bound
+//                flip of the entering variable: a step of its own kind); row p_g carried through the chain -> scaled
+//                pivot row; objective row, devex weights, statuses and bounds of the columns as the step leaves them;
+//                pricing partials for step g+1
+//   k_fbc2       the bulk pass
+// What two rounds of in-kernel stamps taught (scripts/fcsdbg.py): a step is a chain of dependent
+// memory round trips, so (1) pointers, geometry and tolerances come by value (ChainArgs): every load whose address is
+// known on entry is requested on entry; (2) loads are unconditional -- indices are clamped, results masked -- because a
+// load behind a run-time condition makes the compiler wait for it on the spot; (3) the description of the pending
+// chain sits in the registers of lanes 0..g-1 of every wave and is broadcast with v_readlane instead of being staged in
+// LDS; (4) what a step changes besides the tableau (basic values, bounds, statuses, objective row, weights) is carried
+// from step to step in two alternating sets of small arrays, so no launch re-derives it from the chain; (5) one
+// barrier per launch; every store at the end.  A chain ends early on: no entering column, the pivot limit, the stall
+// limit (Bland's rule and the perturbation stay with the generic step), an unbounded ray.
 
 // value of lane `l` (wave-uniform l) in every lane, through the scalar unit: no LDS, no barrier
 __device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
@@ -2163,494 +1591,487 @@ __device__ __forceinline__ double rl_d(double x, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
   return __hiloint2double(hi, lo);
 }
-// block-wide arg-best with ONE barrier: every wave leaves its best in its own slot, every wave reduces the four slots
+// block-wide arg-best with ONE barrier: every wave leaves its best in its own slot, every wave reduces the four slots;
+// returns the winning wave's number in *bw
 template <int MODE>
-__device__ __forceinline__ Cand block_best1(Cand x, Cand *slots) {
-  x = wave_best<MODE>(x);
-  if ((TIDX & 63) == 0) slots[TIDX >> 6] = x;
+__device__ __forceinline__ Cand block_best1(Cand x, Cand *slots, int *bw) {
+  if ((TIDX & 63) == 0) slots[TIDX >> 6] = x; // x: the wave's best, already uniform within the wave
   __syncthreads();
   Cand r = slots[0];
+  int w0 = 0;
 #pragma unroll
   for (int w = 1; w < 4; w++) {
     const Cand y = slots[w];
-    if (cand_better<MODE>(y, r)) r = y;
+    if (cand_better<MODE>(y, r)) {
+      r = y;
+      w0 = w;
+    }
   }
+  *bw = w0;
   return r;
 }
 
-// Every block keeps ONE candidate column alive from step to step: the set a launch reads holds, per block, the column
-// of the block's last candidate carried through every step so far.  When the block's best column is still that one
-// (the usual case for a block that did not win), the new step is applied to the kept column -- no gather, no carry.
-// Only a block whose candidate changed (the winner always) gathers a column from the tableau and carries it through
-// the whole pending chain.
-// How the kernel is laid out follows what the first versions measured (in-kernel stamps, scripts/fcsdbg.py): every load
-// whose address is known on entry is requested on entry, unconditionally (indices are clamped, results masked: a load
-// behind a run-time condition makes the compiler wait for it on the spot); the description of the pending chain sits in
-// the registers of lanes 0..g-1 of every wave and is broadcast with v_readlane (no LDS round trip per step); two
-// barriers in all; every store at the end.
-template <int U> // rows per lane in the column phase
-__global__ __launch_bounds__(256) void k_fcs(const FcsArgs A, int g, int boot) {
-  __shared__ Cand s_best[4], s_ratio[4];
-  __shared__ double s_pay[4][6];
-  Ctl *const c = A.c;
-  const int ncb = (int)gridDim.x, R = (int)gridDim.y, b = (int)blockIdx.x, rg = (int)blockIdx.y;
-  const bool lead = (b == 0 && rg == 0 && TIDX == 0);
+enum : int { PPF_SCORE = 0, PPF_Q, PPF_SDIR, PPF_DQ, PPF_WQ, PPF_LB, PPF_UB, PPF_FQ };
+enum : int { RPF_K1 = 0, RPF_K2, RPF_IDX, RPF_AUX };
+
+// a column block's best entering column and what the column phase needs of it, taken from the lane that owns it;
+// thread 0 writes the block's pricing partial.  Ends with the launch's one barrier.
+__device__ __forceinline__ void publish_pricing(const ChainArgs &A, Cand best, int b, double d, double w, double lbj, double ubj, int f,
+                                                Cand *slots, double (*pay)[5]) {
   const int lane = TIDX & 63, wave = TIDX >> 6;
-  const int m = A.m, n = A.n, mcap1 = A.mcap1;
-  const size_t ld = (size_t)A.ld;
-  double *const T = A.T;
-  const double tol = A.tol_dj, sgn = A.sgn, tp = A.tol_piv;
-  const int stall_limit = A.stall_limit;
-  const int xr = g & 1, xw = boot ? 0 : (xr ^ 1); // the sets this launch reads / writes
-  const int j = b * 256 + TIDX;
-  const bool act = (j <= n);
-  const int jc = act ? j : n; // clamped: loads are unconditional
-  unsigned long long *const dbg = c->dbg;
-#define FCS_STAMP(k) do { if (dbg && lead) dbg[(size_t)(boot ? KCH : g) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-  FCS_STAMP(0);
-  // ---- level 1: everything whose address is known on entry, requested together
-  const int done = c->done, fstate = c->fstate, epoch = c->pc_epoch, budget = c->budget;
-  int ri[U], rc[U]; // this lane's rows (0 = none) / clamped for the loads
-  double a[U], be[U], lb[U], ub[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int i = 1 + rg * (256 * U) + TIDX + 256 * u;
-    ri[u] = (i <= m) ? i : 0;
-    rc[u] = (i <= m) ? i : m;
-    lb[u] = A.blb[rc[u]];
-    ub[u] = A.bub[rc[u]];
+  const Cand wb = wave_bcast_best<0>(best);
+  const int ol = wb.idx ? ((wb.idx - b * 256) & 63) : 0;
+  const double p0 = rl_d(d, ol), p1 = rl_d(w, ol), p2 = rl_d(lbj, ol), p3 = rl_d(ubj, ol);
+  const int p4 = rl_i(f, ol);
+  if (lane == 0) {
+    pay[wave][0] = p0;
+    pay[wave][1] = p1;
+    pay[wave][2] = p2;
+    pay[wave][3] = p3;
+    pay[wave][4] = (double)p4;
   }
-  int nsteps = 0; // steps of the pending chain once this launch has added its own
-  double dnew = 0.0, wnew = 1.0, lbj = 0.0, ubj = 0.0, sj = 0.0;
-  int fnew = MVX_NS;
-  int cachedq = 0; // the column this block's kept candidate belongs to
-  double cig[U];   // this launch's step: the pivot column's entries of this lane's rows
+  int bw;
+  const Cand bb = block_best1<0>(wb, slots, &bw);
+  if (TIDX == 0) {
+    double *pp = A.pp + b;
+    const size_t st = A.ppstride;
+    pp[PPF_SCORE * st] = bb.k1;
+    pp[PPF_Q * st] = (double)bb.idx;
+    pp[PPF_SDIR * st] = (double)bb.aux;
+    pp[PPF_DQ * st] = pay[bw][0];
+    pp[PPF_WQ * st] = pay[bw][1];
+    pp[PPF_LB * st] = pay[bw][2];
+    pp[PPF_UB * st] = pay[bw][3];
+    pp[PPF_FQ * st] = pay[bw][4];
+  }
+}
+
+// Start of a call.  A call that has just begun (phase PH_START, no bound edits waiting) is taken from its first pivot:
+// every block repeats select_step's opening check -- no basic variable outside its bounds by more than the tolerance --
+// and, if that holds, the primal devex weights restart from one exactly as the generic step's `fresh_primal` does.
+// Otherwise (dual simplex, phase 1, Bland's rule in force) the pipeline is turned off and its launches return at once.
+__global__ __launch_bounds__(256) void k_pboot(const ChainArgs A) {
+  __shared__ Cand s_slots[4];
+  __shared__ double s_pay[4][5];
+  Ctl *const c = A.c;
+  const int b = (int)blockIdx.x;
+  const bool lead = (b == 0 && TIDX == 0);
+  const int m = A.m, n = A.n;
+  const size_t ld = (size_t)A.ld;
+  const double *const T = A.T;
+  const int phase = c->phase;
+  const bool fresh = (phase == PH_START);
+  if (c->done != D_RUN || c->stall >= A.stall_limit || !(phase == PH_PRIMAL2 || (fresh && c->n_edits == 0))) { // no Bland pricing here
+    if (lead) c->fstate = F_OFF;
+    return;
+  }
+  const int src = c->curA & 1;
+  const int i = 1 + b * 256 + TIDX, ic = (i <= m) ? i : m;
+  const double bi = T[(size_t)ic * ld];
+  if (fresh) {
+    const double tolb = A.tol_bnd;
+    int bad = 0;
+    for (int i0 = 1 + TIDX; i0 <= m; i0 += 256 * 8) {
+      double xb[8], xl[8], xu[8];
 #pragma unroll
-  for (int u = 0; u < U; u++) cig[u] = 0.0;
-  // the pending chain, one step per lane (lanes 0..g-1 of every wave), and this launch's own step (uniform)
-  int rk = 0, rp = 0, rq = 0, rlf = 0;
-  double rpiv = 1.0, rxq = 0.0, rs0 = 0.0, rdelta = 0.0, relb = 0.0, reub = 0.0, rllb = 0.0, rlub = 0.0, rip = 1.0;
-  int ck = ST_NONE, cp_ = 0, cq_ = 0;
-  double cpiv = 1.0, cxq = 0.0, cs0 = 0.0, cdelta = 0.0, celb = 0.0, ceub = 0.0, cip = 1.0;
-  if (boot) {
-    if (done != D_RUN) return;
-    const int phase = c->phase;
-    const bool fresh = (phase == PH_START);
-    if (c->stall >= stall_limit || !(phase == PH_PRIMAL2 || (fresh && c->n_edits == 0))) { // no Bland pricing here
+      for (int u = 0; u < 8; u++) {
+        const int r = i0 + 256 * u;
+        const int rc = (r <= m) ? r : m;
+        xb[u] = T[(size_t)rc * ld];
+        xl[u] = A.blb[rc];
+        xu[u] = A.bub[rc];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (xl[u] > -INFINITY && xb[u] < xl[u] - tolb * (1.0 + fabs(xl[u]))) bad = 1;
+        if (xu[u] < INFINITY && xb[u] > xu[u] + tolb * (1.0 + fabs(xu[u]))) bad = 1;
+      }
+    }
+    if (__syncthreads_or(bad)) { // not primal feasible: the generic step decides between the dual simplex and phase 1
       if (lead) c->fstate = F_OFF;
       return;
     }
-    const int src = c->curA & 1;
-#pragma unroll
-    for (int u = 0; u < U; u++) be[u] = T[(size_t)rc[u] * ld];
-    if (fresh) { // select_step's opening check: is the starting basis primal feasible?
-      const double tolb = A.tol_bnd;
-      int bad = 0;
-      for (int i0 = 1 + TIDX; i0 <= m; i0 += 256 * 8) {
-        double xb[8], xl[8], xu[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int i = i0 + 256 * u;
-          const int ic = (i <= m) ? i : m;
-          xb[u] = T[(size_t)ic * ld];
-          xl[u] = A.blb[ic];
-          xu[u] = A.bub[ic];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          if (xl[u] > -INFINITY && xb[u] < xl[u] - tolb * (1.0 + fabs(xl[u]))) bad = 1;
-          if (xu[u] < INFINITY && xb[u] > xu[u] + tolb * (1.0 + fabs(xu[u]))) bad = 1;
-        }
-      }
-      if (__syncthreads_or(bad)) { // the generic step decides between the dual simplex and phase 1
-        if (lead) c->fstate = F_OFF;
-        return;
-      }
+  }
+  if (i <= m) A.betab[i] = bi;
+  const int j = b * 256 + TIDX;
+  if (b < A.ncb) {
+    const bool act = (j <= n);
+    const int jc = act ? j : n;
+    const double d = T[jc];
+    const double w = fresh ? 1.0 : A.pw[src][jc];
+    const int f = (act && j >= 1) ? A.nflag[jc] : MVX_NS;
+    const double lbj = A.nlb[jc], ubj = A.nub[jc];
+    if (act) {
+      A.pw[0][j] = w; // both sets current: the generic step reads pw[curA & 1]
+      A.pw[1][j] = w;
     }
-    dnew = T[jc];
-    wnew = fresh ? 1.0 : A.pw[src][jc];
-    if (j >= 1) {
-      fnew = A.nflag[jc];
-      lbj = A.nlb[jc];
-      ubj = A.nub[jc];
+    Cand best{0.0, 0.0, 0, 0};
+    if (f != MVX_NS) {
+      Cand x{0.0, 0.0, 0, 0};
+      if (price_col(f, A.sgn * d, A.tol_dj, j, w, x)) best = x;
     }
-    if (lead) {
-      c->fstate = F_RUN;
-      c->step = ST_NONE;
-      c->pc_n = 0;
-    }
+    publish_pricing(A, best, b, d, w, lbj, ubj, f, s_slots, s_pay);
+  }
+  if (lead) {
+    c->fstate = F_RUN;
+    c->step = ST_NONE;
+    c->pc_n = 0;
+  }
+}
+
+// the chain so far, one step per lane (lanes 0..g-1 of every wave; lanes past it re-read its last step: no guard)
+struct LaneRec {
+  int kind, p, q;
+  double piv, xq, ip; // ip = 1 / piv
+};
+__device__ __forceinline__ LaneRec lane_rec(const Ctl *c, int g) {
+  const int lane = TIDX & 63;
+  const int rl = (lane < g) ? lane : (g > 0 ? g - 1 : 0);
+  LaneRec r;
+  r.kind = c->ch_kind[rl];
+  r.p = c->ch_p[rl];
+  r.q = c->ch_q[rl];
+  r.piv = c->ch_piv[rl];
+  r.xq = c->ch_xq[rl];
+  r.ip = 1.0;
+  return r;
+}
+
+// Column phase of step g.
+__global__ __launch_bounds__(256) void k_pc(const ChainArgs A, int g) {
+  __shared__ Cand s_slots[4];
+  Ctl *const c = A.c;
+  const int b = (int)blockIdx.x;
+  const bool lead = (b == 0 && TIDX == 0);
+  const int lane = TIDX & 63;
+  const int m = A.m, ncb = A.ncb;
+  const size_t ld = (size_t)A.ld;
+  const double *const T = A.T;
+  unsigned long long *const dbg = c->dbg;
+#define PC_STAMP(k) do { if (dbg && lead) dbg[(size_t)g * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  PC_STAMP(0);
+  // ---- entry: everything whose address is known
+  const int done = c->done, fstate = c->fstate, epoch = c->pc_epoch, budget = c->budget;
+  const int okprev = g ? c->ch_ok[g - 1] : 0;
+  const int stall = g ? c->ch_stall[g - 1] : c->stall;
+  const int used = g ? c->ch_cnt[g - 1] : 0;
+  const int i = 1 + b * 256 + TIDX;
+  const bool act = (i <= m);
+  const int ic = act ? i : m;
+  // the row side as of step g-1 (set (g-1) & 1; the handle's own arrays while the chain has no step) ...
+  const int xs = (g - 1) & 1;
+  const double *bsrc = (g <= 1) ? A.betab : A.betak[xs], *lsrc = (g <= 1) ? A.blb : A.blbk[xs], *usrc = (g <= 1) ? A.bub : A.bubk[xs];
+  double be = bsrc[ic], lb = lsrc[ic], ub = usrc[ic];
+  // ... step g-1 itself, which this launch applies to it ...
+  const int gp = g ? g - 1 : 0;
+  const int pk = c->ch_kind[gp], pp_ = c->ch_p[gp];
+  const double pxq = c->ch_xq[gp], ps0 = c->ch_s0[gp], pdelta = c->ch_delta[gp], pelb = c->ch_elb[gp], peub = c->ch_eub[gp];
+  // ... this lane's row of the chain's pivot columns ...
+  double ca[16], cb[16];
+#pragma unroll
+  for (int s = 0; s < 16; s++) ca[s] = A.colq0[(size_t)s * A.cstride + ic];
+  if (g > 16) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) cb[s] = A.colq0[(size_t)(16 + s) * A.cstride + ic];
   } else {
-    const int okprev = g ? c->ch_ok[g - 1] : 0;
-    const int stall = g ? c->ch_stall[g - 1] : c->stall;
-    const int used = g ? c->ch_cnt[g - 1] : 0;
-    // candidates: every wave reduces them on its own (no barrier); a lane keeps the whole record of its best one
-    SpecPart mine{0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0};
-    Cand myr{0.0, 0.0, 0, 0};
-    int myb = 0;
-    {
-      const SpecPart *sp = A.sp[xr];
-      const Cand *spr = A.spr[xr];
-      for (int t = lane; t < ncb; t += 64) {
-        const SpecPart x = sp[t];
-        Cand rr = spr[(size_t)t * R];
-        for (int k = 1; k < R; k++) {
-          const Cand y = spr[(size_t)t * R + k];
-          if (cand_better<1>(y, rr)) rr = y;
-        }
-        if (x.q != 0 && (mine.q == 0 || x.score > mine.score || (x.score == mine.score && x.q < mine.q))) {
-          mine = x;
-          myr = rr;
-          myb = t;
-        }
-      }
-    }
-    cachedq = A.sp[xr][b].q;
-    // this lane's column as the last step left it; its entries of the chain's scaled pivot rows (all KCH rows of that
-    // buffer exist: the loads need no guard); its rows of the block's kept candidate and of column 0
-    double ta[16], tb[16];
-    const double dj = A.drow[xr][jc], wj = A.pw[xr][jc];
-    int fj = A.nflag[jc];
-    lbj = A.nlb[jc];
-    ubj = A.nub[jc];
-    if (j == 0 || !act) fj = MVX_NS;
 #pragma unroll
-    for (int s = 0; s < 16; s++) ta[s] = A.srow0[(size_t)s * A.sstride + jc];
-    if (g > 16) {
-#pragma unroll
-      for (int s = 0; s < 16; s++) tb[s] = A.srow0[(size_t)(16 + s) * A.sstride + jc];
-    } else {
-#pragma unroll
-      for (int s = 0; s < 16; s++) tb[s] = 0.0;
-    }
-    {
-      const double *colp = A.spcol[xr] + (size_t)b * mcap1, *bk = A.betak[xr];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        a[u] = colp[rc[u]];
-        be[u] = bk[rc[u]];
-      }
-    }
-    // the chain so far: lane l of every wave fetches step l (lanes past the chain re-read its last step: no guard)
-    const int rl = (lane < g) ? lane : (g > 0 ? g - 1 : 0);
-    rk = c->ch_kind[rl];
-    rp = c->ch_p[rl];
-    rq = c->ch_q[rl];
-    rlf = c->ch_lf[rl];
-    rpiv = c->ch_piv[rl];
-    rxq = c->ch_xq[rl];
-    rs0 = c->ch_s0[rl];
-    rdelta = c->ch_delta[rl];
-    relb = c->ch_elb[rl];
-    reub = c->ch_eub[rl];
-    rllb = c->ch_llb[rl];
-    rlub = c->ch_lub[rl];
-    if (done != D_RUN || fstate != F_RUN) return;
-    if (g > 0 && okprev != epoch) return; // the chain ended before this step
-    // winner
-    Cand key{mine.q ? mine.score : 0.0, 0.0, mine.q, lane};
-    key = wave_bcast_best<0>(key);
-    const int q = key.idx, wl = key.aux;
-    const bool none = (q == 0);
-    const int left = (budget < 0) ? 1 : budget - used;
-    if (none || left <= 0 || stall >= stall_limit) {
-      if (lead) {
-        if (g == 0) {
-          c->fstate = F_STOP;
-          c->phase = PH_PRIMAL2;
-          // the pivot limit with an entering column still on offer and nothing perturbed is what the generic step
-          // would report as it stands (select_step: price, then `budget == 0` -> D_ITLIM)
-          if (!none && left <= 0 && stall < stall_limit && !c->perturbed) {
-            c->done = D_ITLIM;
-            c->step = ST_NONE;
-          }
-        }
-      }
-      return;
-    }
-    const int sdir = rl_i(mine.sdir, wl), bwin = rl_i(myb, wl), fq = rl_i(mine.fq, wl);
-    const double dq = rl_d(mine.dq, wl), wq = rl_d(mine.wq, wl), lbq = rl_d(mine.lbq, wl), ubq = rl_d(mine.ubq, wl);
-    const int p = rl_i(myr.idx, wl), p_up = rl_i(myr.aux, wl);
-    const double tstep = rl_d(myr.k1, wl);
-    bool flip = false;
-    double tf = 0.0;
-    if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
-      tf = ubq - lbq;
-      if (p == 0 || tf <= tstep) flip = true;
-    }
-    if (!flip && p == 0) { // unbounded ray: the generic path reports it
-      if (lead && g == 0) {
-        c->fstate = F_STOP;
-        c->phase = PH_PRIMAL2;
-      }
-      return;
-    }
-    const double *const colw = A.spcol[xr] + (size_t)bwin * mcap1; // the winner's column as of this step
-    FCS_STAMP(1);
-    // ---- level 2: what depends on the winner
-    const int pr = flip ? 1 : p;
-    const double piv = colw[pr];
-    const double val0 = T[(size_t)pr * ld + jc];
-    const double val00 = A.betak[xr][pr]; // the leaving row's basic value as of this step
-    double plb = A.blb[pr], pub = A.bub[pr];
-#pragma unroll
-    for (int u = 0; u < U; u++) cig[u] = colw[rc[u]];
-    const double rcp = (A.colq0 + (size_t)rl * A.cstride)[pr]; // step l's pivot-column entry of the leaving row
-    rip = xdiv(1.0, rpiv);
-    const double rcd = xdiv(rcp, rpiv);
-    FCS_STAMP(2);
-    // the leaving row's entry in this lane's column carried through the chain so far; statuses / bounds as the chain
-    // so far left them
-    double val = val0;
-#define FCS_ROWSTEP(S, TV)                                                                                         \
-  if ((S) < g) {                                                                                                   \
-    const int lk = rl_i(rk, (S)), lp = rl_i(rp, (S)), lq = rl_i(rq, (S));                                          \
-    const double cp = rl_d(rcp, (S));                                                                              \
-    if (lk == ST_FLIP) {                                                                                           \
-      if (lq == j) fj = rl_i(rlf, (S));                                                                            \
-    } else {                                                                                                       \
-      if (lp == p) val = (j == lq) ? rl_d(rip, (S)) : ((j == 0) ? rl_d(rxq, (S)) - (TV) : -(TV));                  \
-      else val = (j == lq) ? rl_d(rcd, (S)) : fma(-cp, (TV), val);                                                 \
-      if (lq == j) {                                                                                               \
-        fj = rl_i(rlf, (S));                                                                                       \
-        lbj = rl_d(rllb, (S));                                                                                     \
-        ubj = rl_d(rlub, (S));                                                                                     \
-      }                                                                                                            \
-      if (lp == pr) {                                                                                              \
-        plb = rl_d(relb, (S));                                                                                     \
-        pub = rl_d(reub, (S));                                                                                     \
-      }                                                                                                            \
-      _Pragma("unroll") for (int u = 0; u < U; u++) if (lp == ri[u]) {                                             \
-        lb[u] = rl_d(relb, (S));                                                                                   \
-        ub[u] = rl_d(reub, (S));                                                                                   \
-      }                                                                                                            \
-    }                                                                                                              \
+    for (int s = 0; s < 16; s++) cb[s] = 0.0;
   }
-#pragma unroll
-    for (int s = 0; s < 16; s++) { FCS_ROWSTEP(s, ta[s]) }
-    if (g > 16) {
-#pragma unroll
-      for (int s = 0; s < 16; s++) { FCS_ROWSTEP(16 + s, tb[s]) }
+  LaneRec rec = lane_rec(c, g);
+  // ... and the pricing partials: every wave reduces them on its own; a lane keeps the whole record of its best one
+  double m_sc = 0.0, m_dq = 0.0, m_wq = 1.0, m_lb = 0.0, m_ub = 0.0;
+  int m_q = 0, m_sd = 0, m_fq = 0;
+  for (int t = lane; t < ncb; t += 64) {
+    const double *pp = A.pp + t;
+    const size_t st = A.ppstride;
+    const double sc = pp[PPF_SCORE * st];
+    const int q = (int)pp[PPF_Q * st];
+    const int sd = (int)pp[PPF_SDIR * st];
+    const double dq = pp[PPF_DQ * st], wq = pp[PPF_WQ * st], l0 = pp[PPF_LB * st], u0 = pp[PPF_UB * st];
+    const int fq = (int)pp[PPF_FQ * st];
+    if (q != 0 && (m_q == 0 || sc > m_sc || (sc == m_sc && q < m_q))) {
+      m_sc = sc; m_q = q; m_sd = sd; m_dq = dq; m_wq = wq; m_lb = l0; m_ub = u0; m_fq = fq;
     }
-#undef FCS_ROWSTEP
-    int stall_new;
-    if (flip) {
-      const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
-      cdelta = (sdir > 0) ? tf : -tf;
-      ck = ST_FLIP;
-      cp_ = 0;
-      cq_ = q;
-      dnew = (j == 0) ? fma(dq, cdelta, dj) : dj; // the objective value moves with the flipped variable
-      wnew = wj;
-      fnew = (j == q) ? nf : fj;
-      sj = 0.0;
-      stall_new = 0;
-      if (lead) c->ch_lf[g] = nf;
-    } else {
-      const double bound = p_up ? pub : plb;
-      const int lf = dev_leave_flag(plb, pub, p_up);
-      cs0 = xdiv(val00 - bound, piv); // what lane 0 of block 0 gets for column 0
-      sj = (j == 0) ? cs0 : xdiv(val, piv);
-      cip = xdiv(1.0, piv);
-      dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dj);
-      if (j == q) {
-        const double cc = xdiv(wq, piv * piv);
-        wnew = cc > 1.0 ? cc : 1.0;
-        lbj = plb; // the leaving variable comes to sit in column q
-        ubj = pub;
-      } else {
-        const double cc = sj * sj * wq;
-        wnew = cc > wj ? cc : wj;
-      }
-      fnew = (j == q) ? lf : fj;
-      ck = ST_PIVOT;
-      cp_ = p;
-      cq_ = q;
-      cpiv = piv;
-      cxq = dev_nb_value(fq, lbq, ubq);
-      celb = lbq;
-      ceub = ubq;
-      stall_new = (tstep <= DEGEN_TOL) ? stall + 1 : 0;
-      if (lead) {
-        c->ch_lf[g] = lf;
-        c->ch_llb[g] = plb;
-        c->ch_lub[g] = pub;
-        c->ch_bound[g] = bound;
-        c->ch_pup[g] = p_up;
-      }
-    }
-    if (!act || j == 0) fnew = MVX_NS;
-    FCS_STAMP(3);
-    if (lead) {
-      c->ch_kind[g] = ck;
-      c->ch_p[g] = cp_;
-      c->ch_q[g] = cq_;
-      c->ch_piv[g] = cpiv;
-      c->ch_xq[g] = cxq;
-      c->ch_s0[g] = cs0;
-      c->ch_delta[g] = cdelta;
-      c->ch_elb[g] = lbq;
-      c->ch_eub[g] = ubq;
-      c->ch_stall[g] = stall_new;
-      c->ch_cnt[g] = used + (flip ? 0 : 1);
-      c->ch_ok[g] = epoch;
-      c->pc_n = g + 1;
+  }
+  if (done != D_RUN || fstate != F_RUN) return;
+  if (g > 0 && okprev != epoch) return; // the chain ended before this step
+  Cand key{m_q ? m_sc : 0.0, 0.0, m_q, lane};
+  key = wave_bcast_best<0>(key);
+  const int q = key.idx, wl = key.aux;
+  const bool none = (q == 0);
+  const int left = (budget < 0) ? 1 : budget - used;
+  if (none || left <= 0 || stall >= A.stall_limit) {
+    if (lead && g == 0) {
+      c->fstate = F_STOP;
       c->phase = PH_PRIMAL2;
-    }
-    nsteps = g + 1;
-  }
-  // ---- level 3: the candidate of this column block for the next step
-  Cand best{0.0, 0.0, 0, 0};
-  if (act && j >= 1) {
-    Cand x{0.0, 0.0, 0, 0};
-    if (price_col(fnew, sgn * dnew, tol, j, wnew, x)) best = x;
-  }
-  {
-    // a wave's best column and what the next launch needs of it, taken from the lane that owns it
-    const Cand wb = wave_bcast_best<0>(best);
-    const int ol = wb.idx ? ((wb.idx - b * 256) & 63) : 0;
-    const double p0 = rl_d(dnew, ol), p1 = rl_d(wnew, ol), p2 = rl_d(lbj, ol), p3 = rl_d(ubj, ol), p5 = rl_d(sj, ol);
-    const int p4 = rl_i(fnew, ol);
-    if (lane == 0) {
-      s_best[wave] = wb;
-      s_pay[wave][0] = p0;
-      s_pay[wave][1] = p1;
-      s_pay[wave][2] = p2;
-      s_pay[wave][3] = p3;
-      s_pay[wave][4] = (double)p4;
-      s_pay[wave][5] = p5;
-    }
-  }
-  __syncthreads();
-  int bw = 0;
-  best = s_best[0];
-#pragma unroll
-  for (int w = 1; w < 4; w++) {
-    const Cand y = s_best[w];
-    if (cand_better<0>(y, best)) {
-      best = y;
-      bw = w;
-    }
-  }
-  FCS_STAMP(4);
-  const int q2 = best.idx, sd2 = best.aux;
-  const double own_d = s_pay[bw][0], own_w = s_pay[bw][1], own_lb = s_pay[bw][2], own_ub = s_pay[bw][3], own_s = s_pay[bw][5];
-  const int own_f = (int)s_pay[bw][4];
-  double *const colo = A.spcol[xw] + (size_t)b * mcap1;
-  const bool keep = (!boot && q2 != 0 && q2 == cachedq); // the kept candidate column is still the block's best
-  if (dbg && TIDX == 0 && rg == 0 && !boot) atomicAdd(&dbg[(size_t)(KCH + 1) * 8 + (keep ? 0 : (q2 ? 1 : 2))], 1ull);
-  if (q2 != 0 && !keep) {
-    // a fresh column: gathered from the tableau as it stands, carried through the steps before this launch's
-    const int q2c = q2;
-    const double sqv = A.srow0[(size_t)((lane < g) ? lane : 0) * A.sstride + q2c]; // its entries of the earlier pivot rows, one per lane
-#pragma unroll
-    for (int u = 0; u < U; u++) a[u] = T[(size_t)rc[u] * ld + q2c];
-    constexpr int SB = (U <= 2) ? 16 : 2; // steps per batch of carry loads
-    for (int l0 = 0; l0 + 1 < nsteps; l0 += SB) {
-      double ci[SB][U];
-#pragma unroll
-      for (int s = 0; s < SB; s++) {
-        const int l = (l0 + s + 1 < nsteps) ? l0 + s : 0;
-        const double *cq = A.colq0 + (size_t)l * A.cstride;
-#pragma unroll
-        for (int u = 0; u < U; u++) ci[s][u] = cq[rc[u]];
-      }
-#pragma unroll
-      for (int s = 0; s < SB; s++) {
-        const int l = l0 + s;
-        if (l + 1 < nsteps) {
-          const int lk = rl_i(rk, l), lp = rl_i(rp, l), lq = rl_i(rq, l);
-          if (lk == ST_PIVOT) {
-            const double sq = rl_d(sqv, l);
-            if (lq == q2) { // a column an earlier step of the chain pivoted on (rare)
-              const double ip = rl_d(rip, l), pv = rl_d(rpiv, l);
-              for (int u = 0; u < U; u++) a[u] = (ri[u] == lp) ? ip : xdiv(ci[s][u], pv);
-            } else {
-#pragma unroll
-              for (int u = 0; u < U; u++) a[u] = (ri[u] == lp) ? -sq : fma(-ci[s][u], sq, a[u]);
-            }
-          }
-        }
+      // the pivot limit with an entering column still on offer and nothing perturbed is what the generic step would
+      // report as it stands (select_step: price, then `budget == 0` -> D_ITLIM)
+      if (!none && left <= 0 && stall < A.stall_limit && !c->perturbed) {
+        c->done = D_ITLIM;
+        c->step = ST_NONE;
       }
     }
+    return;
   }
-  FCS_STAMP(5);
-  // this launch's own step applied to the candidate column and to column 0
-  if (nsteps > 0) {
-    if (ck == ST_FLIP) {
+  const int sdir = rl_i(m_sd, wl);
+  PC_STAMP(1);
+  // ---- what depends on the entering column: its entries of this lane's row and of the chain's scaled pivot rows
+  double a = T[(size_t)ic * ld + q];
+  const double sqv = A.srow0[(size_t)((lane < g) ? lane : 0) * A.sstride + q];
+  rec.ip = xdiv(1.0, rec.piv);
+  // the row side as of step g
+  double cg1 = 0.0; // this lane's entry of step g-1's pivot column
 #pragma unroll
-      for (int u = 0; u < U; u++) be[u] = fma(cig[u], cdelta, be[u]);
-    } else {
-      if (q2 != 0) {
-        if (cq_ == q2) {
-          for (int u = 0; u < U; u++) a[u] = (ri[u] == cp_) ? cip : xdiv(cig[u], cpiv);
-        } else {
-#pragma unroll
-          for (int u = 0; u < U; u++) a[u] = (ri[u] == cp_) ? -own_s : fma(-cig[u], own_s, a[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const bool isp = (ri[u] == cp_);
-        be[u] = isp ? cxq - cs0 : fma(-cig[u], cs0, be[u]);
-        if (isp) {
-          lb[u] = celb;
-          ub[u] = ceub;
-        }
-      }
-    }
+  for (int s = 0; s < 16; s++) {
+    if (s == g - 1) cg1 = ca[s];
+    if (16 + s == g - 1) cg1 = cb[s];
   }
-  FCS_STAMP(6);
+  if (g > 0) {
+    if (pk == ST_FLIP) be = fma(cg1, pdelta, be);
+    else if (i == pp_) {
+      be = pxq - ps0;
+      lb = pelb;
+      ub = peub;
+    } else
+      be = fma(-cg1, ps0, be);
+  }
+  PC_STAMP(2);
+  // column q carried through steps 0..g-1
+#define PC_COLSTEP(S, CV)                                                          \
+  if ((S) < g) {                                                                   \
+    const int lk = rl_i(rec.kind, (S));                                            \
+    if (lk == ST_PIVOT) {                                                          \
+      const int lp = rl_i(rec.p, (S)), lq = rl_i(rec.q, (S));                      \
+      const double sq = rl_d(sqv, (S));                                            \
+      if (lq == q) a = (i == lp) ? rl_d(rec.ip, (S)) : xdiv((CV), rl_d(rec.piv, (S))); \
+      else a = (i == lp) ? -sq : fma(-(CV), sq, a);                                \
+    }                                                                              \
+  }
+#pragma unroll
+  for (int s = 0; s < 16; s++) { PC_COLSTEP(s, ca[s]) }
+  if (g > 16) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) { PC_COLSTEP(16 + s, cb[s]) }
+  }
+#undef PC_COLSTEP
+  PC_STAMP(3);
   Cand rb{0.0, 0.0, 0, 0};
-  if (q2 != 0) {
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (ri[u]) {
-        Cand x{0.0, 0.0, 0, 0};
-        if (ratio_row(a[u], sd2, be[u], lb[u], ub[u], 0, tp, ri[u], x) && cand_better<1>(x, rb)) rb = x;
-      }
-    }
+  if (act) {
+    Cand x{0.0, 0.0, 0, 0};
+    if (ratio_row(a, sdir, be, lb, ub, 0, A.tol_piv, i, x)) rb = x;
   }
-  rb = block_best1<1>(rb, s_ratio);
-  // ---- every store of the launch (nothing above waits for one)
-  if (act && rg == 0) {
-    if (boot) {
-      A.drow[0][j] = dnew;
-      A.pw[0][j] = wnew; // both sets current: the generic step reads pw[curA & 1]
-      A.pw[1][j] = wnew;
-    } else {
-      A.srow0[(size_t)g * A.sstride + j] = sj;
-      A.drow[xw][j] = dnew;
-      A.pw[xw][j] = (j >= 1) ? wnew : 1.0;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    if (ri[u]) {
-      if (q2 != 0) colo[ri[u]] = a[u];
-      if (b == 0) {
-        A.betak[xw][ri[u]] = be[u];
-        if (nsteps > 0) A.colq0[(size_t)(nsteps - 1) * A.cstride + ri[u]] = cig[u]; // the step's pivot column joins the chain
-      }
+  int bw;
+  rb = block_best1<1>(wave_bcast_best<1>(rb), s_slots, &bw);
+  PC_STAMP(4);
+  // ---- every store of the launch
+  if (act) {
+    A.colq0[(size_t)g * A.cstride + i] = a;
+    if (g > 0) {
+      A.betak[g & 1][i] = be;
+      A.blbk[g & 1][i] = lb;
+      A.bubk[g & 1][i] = ub;
     }
   }
   if (TIDX == 0) {
-    A.spr[xw][(size_t)b * R + rg] = rb;
-    if (rg == 0) {
-      if (q2 != 0) {
-        colo[0] = own_d;
-        A.sp[xw][b] = SpecPart{best.k1, q2, sd2, own_d, own_w, own_lb, own_ub, own_f, 0};
-      } else {
-        A.sp[xw][b] = SpecPart{0.0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0};
-      }
-    }
+    double *rp = A.rp + b;
+    const size_t st = A.rpstride;
+    rp[RPF_K1 * st] = rb.k1;
+    rp[RPF_K2 * st] = rb.k2;
+    rp[RPF_IDX * st] = (double)rb.idx;
+    rp[RPF_AUX * st] = (double)rb.aux;
   }
-  FCS_STAMP(7);
-#undef FCS_STAMP
+  if (lead) {
+    c->hd_q[g] = q;
+    c->hd_sdir[g] = sdir;
+    c->hd_fq[g] = rl_i(m_fq, wl);
+    c->hd_dq[g] = rl_d(m_dq, wl);
+    c->hd_wq[g] = rl_d(m_wq, wl);
+    c->hd_lbq[g] = rl_d(m_lb, wl);
+    c->hd_ubq[g] = rl_d(m_ub, wl);
+    c->ch_okc[g] = epoch;
+    c->phase = PH_PRIMAL2;
+  }
+  PC_STAMP(5);
+#undef PC_STAMP
 }
 
-typedef const double __attribute__((address_space(4))) *kconst_f64; // read-only for the whole launch: scalar loads
+// Row phase of step g.
+__global__ __launch_bounds__(256) void k_pr(const ChainArgs A, int g) {
+  __shared__ Cand s_slots[4];
+  __shared__ double s_pay[4][5];
+  Ctl *const c = A.c;
+  const int b = (int)blockIdx.x;
+  const bool lead = (b == 0 && TIDX == 0);
+  const int lane = TIDX & 63;
+  const int n = A.n, nrb = A.nrb;
+  const size_t ld = (size_t)A.ld;
+  const double *const T = A.T;
+  unsigned long long *const dbg = c->dbg;
+#define PR_STAMP(k) do { if (dbg && lead) dbg[(size_t)g * 16 + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  PR_STAMP(0);
+  // ---- entry
+  const int done = c->done, fstate = c->fstate, epoch = c->pc_epoch;
+  const int okc = c->ch_okc[g];
+  const int stall = g ? c->ch_stall[g - 1] : c->stall;
+  const int used = g ? c->ch_cnt[g - 1] : 0;
+  const int q = c->hd_q[g], sdir = c->hd_sdir[g], fq = c->hd_fq[g];
+  const double dq = c->hd_dq[g], wq = c->hd_wq[g], lbq = c->hd_lbq[g], ubq = c->hd_ubq[g];
+  const int j = b * 256 + TIDX;
+  const bool act = (j <= n);
+  const int jc = act ? j : n;
+  // the column side as of step g (set g & 1; the handle's own arrays while the chain has no step)
+  const int xr = g & 1, xw = xr ^ 1;
+  const double dj = (g == 0) ? T[jc] : A.drowk[xr][jc];
+  const double wj = (g == 0) ? A.pw[0][jc] : A.pwk[xr][jc];
+  int fj = (g == 0) ? A.nflag[jc] : A.nflagk[xr][jc];
+  double lbj = (g == 0) ? A.nlb[jc] : A.nlbk[xr][jc], ubj = (g == 0) ? A.nub[jc] : A.nubk[xr][jc];
+  if (!act || j == 0) fj = MVX_NS;
+  // this lane's entries of the chain's scaled pivot rows (all KCH rows of that buffer exist: no guard)
+  double ta[16], tb[16];
+#pragma unroll
+  for (int s = 0; s < 16; s++) ta[s] = A.srow0[(size_t)s * A.sstride + jc];
+  if (g > 16) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) tb[s] = A.srow0[(size_t)(16 + s) * A.sstride + jc];
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; s++) tb[s] = 0.0;
+  }
+  LaneRec rec = lane_rec(c, g);
+  const int rl = (lane < g) ? lane : (g > 0 ? g - 1 : 0);
+  // ratio-test partials: every wave reduces them on its own
+  Cand rc{0.0, 0.0, 0, 0};
+  for (int t = lane; t < nrb; t += 64) {
+    const double *rp = A.rp + t;
+    const size_t st = A.rpstride;
+    Cand x{rp[RPF_K1 * st], rp[RPF_K2 * st], (int)rp[RPF_IDX * st], (int)rp[RPF_AUX * st]};
+    if (cand_better<1>(x, rc)) rc = x;
+  }
+  if (done != D_RUN || fstate != F_RUN || okc != epoch) return;
+  rc = wave_bcast_best<1>(rc);
+  const int p = rc.idx, p_up = rc.aux;
+  const double tstep = rc.k1;
+  bool flip = false;
+  double tf = 0.0;
+  if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+    tf = ubq - lbq;
+    if (p == 0 || tf <= tstep) flip = true;
+  }
+  if (!flip && p == 0) { // unbounded ray: the generic path reports it
+    if (lead && g == 0) c->fstate = F_STOP;
+    return;
+  }
+  PR_STAMP(1);
+  // ---- what depends on the leaving row
+  const int pr = flip ? 1 : p;
+  const double val0 = T[(size_t)pr * ld + jc];
+  const double piv = A.colq0[(size_t)g * A.cstride + pr];
+  const double bp = (g == 0) ? A.betab[pr] : A.betak[xr][pr];
+  const double plb = (g == 0) ? A.blb[pr] : A.blbk[xr][pr], pub = (g == 0) ? A.bub[pr] : A.bubk[xr][pr];
+  const double rcp = A.colq0[(size_t)rl * A.cstride + pr]; // step l's pivot-column entry of the leaving row
+  rec.ip = xdiv(1.0, rec.piv);
+  const double rcd = xdiv(rcp, rec.piv);
+  PR_STAMP(2);
+  double sj = 0.0, dnew, wnew;
+  int fnew, kind, lf = 0, stall_new;
+  double delta = 0.0, bound = 0.0, s0 = 0.0, xq = 0.0;
+  if (flip) {
+    const int nf = (sdir > 0) ? MVX_NU : MVX_NL;
+    delta = (sdir > 0) ? tf : -tf;
+    kind = ST_FLIP;
+    lf = nf;
+    dnew = (j == 0) ? fma(dq, delta, dj) : dj; // the objective value moves with the flipped variable
+    wnew = wj;
+    fnew = (j == q) ? nf : fj;
+    stall_new = 0;
+  } else {
+    // the leaving row's entry in this lane's column, carried through the chain so far
+    double val = val0;
+#define PR_ROWSTEP(S, TV)                                                                              \
+  if ((S) < g) {                                                                                       \
+    const int lk = rl_i(rec.kind, (S));                                                                \
+    if (lk == ST_PIVOT) {                                                                              \
+      const int lp = rl_i(rec.p, (S)), lq = rl_i(rec.q, (S));                                          \
+      if (lp == p) val = (j == lq) ? rl_d(rec.ip, (S)) : -(TV);                                        \
+      else val = (j == lq) ? rl_d(rcd, (S)) : fma(-rl_d(rcp, (S)), (TV), val);                         \
+    }                                                                                                  \
+  }
+#pragma unroll
+    for (int s = 0; s < 16; s++) { PR_ROWSTEP(s, ta[s]) }
+    if (g > 16) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) { PR_ROWSTEP(16 + s, tb[s]) }
+    }
+#undef PR_ROWSTEP
+    bound = p_up ? pub : plb;
+    lf = dev_leave_flag(plb, pub, p_up);
+    s0 = xdiv(bp - bound, piv); // what lane 0 of block 0 gets for column 0
+    sj = (j == 0) ? s0 : xdiv(val, piv);
+    dnew = (j == q) ? xdiv(dq, piv) : fma(-dq, sj, dj);
+    if (j == q) {
+      const double cc = xdiv(wq, piv * piv);
+      wnew = cc > 1.0 ? cc : 1.0;
+      lbj = plb; // the leaving variable comes to sit in column q
+      ubj = pub;
+    } else {
+      const double cc = sj * sj * wq;
+      wnew = cc > wj ? cc : wj;
+    }
+    fnew = (j == q) ? lf : fj;
+    kind = ST_PIVOT;
+    xq = dev_nb_value(fq, lbq, ubq);
+    stall_new = (tstep <= DEGEN_TOL) ? stall + 1 : 0;
+  }
+  if (!act || j == 0) fnew = MVX_NS;
+  PR_STAMP(3);
+  // pricing partial for step g+1
+  Cand best{0.0, 0.0, 0, 0};
+  if (fnew != MVX_NS) {
+    Cand x{0.0, 0.0, 0, 0};
+    if (price_col(fnew, A.sgn * dnew, A.tol_dj, j, wnew, x)) best = x;
+  }
+  publish_pricing(A, best, b, dnew, wnew, lbj, ubj, fnew, s_slots, s_pay);
+  PR_STAMP(4);
+  // ---- every store of the launch
+  if (act) {
+    A.srow0[(size_t)g * A.sstride + j] = sj;
+    A.drowk[xw][j] = dnew;
+    A.pwk[xw][j] = (j >= 1) ? wnew : 1.0;
+    A.nflagk[xw][j] = (j >= 1) ? fnew : MVX_NS;
+    A.nlbk[xw][j] = lbj;
+    A.nubk[xw][j] = ubj;
+  }
+  if (lead) {
+    c->ch_kind[g] = kind;
+    c->ch_p[g] = flip ? 0 : p;
+    c->ch_q[g] = q;
+    c->ch_lf[g] = lf;
+    c->ch_piv[g] = flip ? 1.0 : piv;
+    c->ch_xq[g] = xq;
+    c->ch_s0[g] = s0;
+    c->ch_delta[g] = delta;
+    c->ch_elb[g] = lbq;
+    c->ch_eub[g] = ubq;
+    c->ch_llb[g] = plb;
+    c->ch_lub[g] = pub;
+    c->ch_bound[g] = bound;
+    c->ch_pup[g] = p_up;
+    c->ch_stall[g] = stall_new;
+    c->ch_cnt[g] = used + (flip ? 0 : 1);
+    c->ch_ok[g] = epoch;
+    c->pc_n = g + 1;
+  }
+  PR_STAMP(5);
+#undef PR_STAMP
+}
+
+// The bulk pass of a chain.  Every entry is loaded once, goes through the chain's steps in registers and is stored
+// once.  What a step needs besides the entry -- the pivot-column entries of the tile's rows, the step's description --
+// is the same for every lane: it comes in through scalar loads (constant address space: nothing in this launch writes
+// it) and sits in SGPRs, so there is no LDS staging and no barrier.
+typedef const double __attribute__((address_space(4))) *kconst_f64;
 template <int TR, int NT>
-__global__ __launch_bounds__(256) void k_fbc2(const FcsArgs A) {
+__global__ __launch_bounds__(256) void k_fbc2(const ChainArgs A) {
   Ctl *const c = A.c;
   if (c->done != D_RUN || c->fstate != F_RUN) return;
   const int nch = c->pc_n;
@@ -2713,29 +2134,15 @@ __global__ __launch_bounds__(256) void k_fbc2(const FcsArgs A) {
 #pragma unroll
     for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
     if (has0) {
-      double *bnew = A.betak[0];
 #pragma unroll
-      for (int r = 0; r < TR; r++) bnew[i0 + r] = v[r].x;
+      for (int r = 0; r < TR; r++) A.betab[i0 + r] = v[r].x;
     }
-    if (blockIdx.y == 0) { // the objective row lives outside the row blocks: back into the tableau
-      const double2 d = *reinterpret_cast<const double2 *>(A.drow[xf] + j0);
-      *reinterpret_cast<double2 *>(A.T + j0) = d;
-      if (xf == 1) { // the next chain starts from set 0
-        *reinterpret_cast<double2 *>(A.drow[0] + j0) = d;
-        *reinterpret_cast<double2 *>(A.pw[0] + j0) = *reinterpret_cast<const double2 *>(A.pw[1] + j0);
-      }
+    if (blockIdx.y == 0) { // the objective row and the weights live outside the row blocks: back to where the other paths read them
+      *reinterpret_cast<double2 *>(A.T + j0) = *reinterpret_cast<const double2 *>(A.drowk[xf] + j0);
+      const double2 w = *reinterpret_cast<const double2 *>(A.pwk[xf] + j0);
+      *reinterpret_cast<double2 *>(A.pw[0] + j0) = w;
+      *reinterpret_cast<double2 *>(A.pw[1] + j0) = w;
     }
-  }
-  if (xf == 1) { // ... and so do the candidates the chain's last step left
-    const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
-    const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + TIDX;
-    const size_t ncol = (size_t)A.ncb * A.mcap1;
-    for (size_t e = me; e < ncol; e += nthr) A.spcol[0][e] = A.spcol[1][e];
-    const size_t nsp = (size_t)A.ncb * (sizeof(SpecPart) / 8), nspr = (size_t)A.ncb * A.R * (sizeof(Cand) / 8);
-    const double *s1 = reinterpret_cast<const double *>(A.sp[1]), *r1 = reinterpret_cast<const double *>(A.spr[1]);
-    double *s0 = reinterpret_cast<double *>(A.sp[0]), *r0 = reinterpret_cast<double *>(A.spr[0]);
-    for (size_t e = me; e < nsp; e += nthr) s0[e] = s1[e];
-    for (size_t e = me; e < nspr; e += nthr) r0[e] = r1[e];
   }
   // The chain's bookkeeping is committed by whichever workgroup finishes last: every other one has read what it needs
   // of the control block by then.
@@ -2768,7 +2175,6 @@ __global__ __launch_bounds__(256) void k_fbc2(const FcsArgs A) {
       c->n_bulk++;
       if (c->budget > 0) c->budget -= piv_n;
       c->stall = c->ch_stall[nch - 1];
-      c->curA = 0; // the current weights are in set 0
       c->pc_n = 0;
       c->pc_epoch++;
       c->pc_arrive = 0;
@@ -3597,63 +3003,17 @@ static int pick_tr(int m, int n) {
 }
 int fused_npb(int n) { return (n + 1 + 255) / 256; }
 int fused_nrb_max(int m) { return (m + 3) / 4; }
-void launch_fboot(Ctl *d_ctl, int n, hipStream_t s) { hipLaunchKernelGGL(k_fboot, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl); }
-void launch_fa(Ctl *d_ctl, int n, hipStream_t s, int probe) { hipLaunchKernelGGL(k_fa, dim3(probe ? 1 : fused_npb(n)), dim3(256), 0, s, d_ctl, probe); }
-void launch_fb(Ctl *d_ctl, int m, int n, hipStream_t s, int boot) {
-  const int pairs = (n + 2) / 2;
-  const int tr = pick_tr(m, n);
-  const int nt = pick_nt(m, n);
-  dim3 grid(boot ? 1 : (pairs + 255) / 256, (m + tr - 1) / tr);
-#define FB_CASE(TR_, HOT_, NT_) \
-  if (tr == TR_ && g_hot == HOT_ && nt == NT_) { hipLaunchKernelGGL((k_fb<TR_, HOT_, NT_, 0>), grid, dim3(256), 0, s, d_ctl); return; }
-  FB_CASE(16, 1, 2) FB_CASE(8, 1, 2) FB_CASE(4, 1, 2) FB_CASE(32, 1, 2) FB_CASE(16, 0, 2) FB_CASE(8, 0, 2) FB_CASE(4, 0, 2) FB_CASE(32, 0, 2) FB_CASE(16, 1, 0) FB_CASE(16, 0, 0) FB_CASE(16, 1, 1) FB_CASE(8, 1, 0) FB_CASE(8, 1, 1) FB_CASE(32, 1, 0) FB_CASE(32, 1, 1)
-  FB_CASE(8, 0, 0) FB_CASE(32, 0, 0) FB_CASE(8, 0, 1) FB_CASE(16, 0, 1) FB_CASE(32, 0, 1)
-  FB_CASE(4, 1, 0) FB_CASE(4, 0, 0) FB_CASE(4, 1, 1) FB_CASE(4, 0, 1)
-#undef FB_CASE
-  std::abort(); // unreachable: every (tr, hot, nt) combination is instantiated above
+int chain_ncb(int n) { return fused_npb(n); }
+int chain_nrb(int m) { return (m + 255) / 256; }
+void launch_pboot(const ChainArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_pboot, dim3(a.ncb > a.nrb ? a.ncb : a.nrb), dim3(256), 0, s, a);
 }
-// step k of a chain: column kernel, then row kernel
-void launch_fc(Ctl *d_ctl, int m, int n, int k, hipStream_t s) {
-  hipLaunchKernelGGL(k_fcc, dim3((m + 255) / 256), dim3(256), 0, s, d_ctl, k);
-  hipLaunchKernelGGL(k_fcr, dim3(fused_npb(n)), dim3(256), 0, s, d_ctl, k);
+void launch_pstep(const ChainArgs &a, int g, hipStream_t s) {
+  hipLaunchKernelGGL(k_pc, dim3(a.nrb), dim3(256), 0, s, a, g);
+  hipLaunchKernelGGL(k_pr, dim3(a.ncb), dim3(256), 0, s, a, g);
 }
-// bulk launch of a chain; returns false when the tuning in force has no chained variant (the caller then uses k_fb)
-bool chain_supported(int m, int n) { return g_hot == 1 && pick_tr(m, n) <= 16; }
-void launch_fbc(Ctl *d_ctl, int m, int n, hipStream_t s) {
-  const int pairs = (n + 2) / 2;
-  const int tr = pick_tr(m, n);
-  const int nt = pick_nt(m, n);
-  dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
-#define FBC_CASE(TR_, NT_) \
-  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fbc<TR_, NT_>), grid, dim3(256), 0, s, d_ctl); return; }
-  FBC_CASE(16, 0) FBC_CASE(16, 1) FBC_CASE(16, 2) FBC_CASE(8, 0) FBC_CASE(8, 1) FBC_CASE(8, 2) FBC_CASE(4, 0) FBC_CASE(4, 1) FBC_CASE(4, 2)
-#undef FBC_CASE
-  std::abort(); // unreachable: chain_supported() gates the call
-}
-// speculative chained primal path: row groups of the candidate column phase (2 rows per lane up to 16 groups, then 16)
-static void fcs_shape(int m, int *U, int *R) {
-  int r = (m + 511) / 512;
-  if (r <= 16) {
-    *U = 2;
-    *R = r < 1 ? 1 : r;
-  } else {
-    *U = 16;
-    *R = (m + 4095) / 4096;
-  }
-}
-int fcs_row_groups(int m) {
-  int U, R;
-  fcs_shape(m, &U, &R);
-  return R;
-}
-void launch_fcs(const FcsArgs &a, int g, int boot, hipStream_t s) {
-  int U, R;
-  fcs_shape(a.m, &U, &R);
-  dim3 grid(a.ncb, R);
-  if (U == 2) hipLaunchKernelGGL((k_fcs<2>), grid, dim3(256), 0, s, a, g, boot);
-  else hipLaunchKernelGGL((k_fcs<16>), grid, dim3(256), 0, s, a, g, boot);
-}
-void launch_fbc2(const FcsArgs &a, hipStream_t s) {
+void launch_pc(const ChainArgs &a, int g, hipStream_t s) { hipLaunchKernelGGL(k_pc, dim3(a.nrb), dim3(256), 0, s, a, g); }
+void launch_fbc2(const ChainArgs &a, hipStream_t s) {
   const int m = a.m, n = a.n;
   const int pairs = (n + 2) / 2;
   int tr = pick_tr(m, n);

@@ -47,16 +47,6 @@ struct Cand {
   int idx, aux;
 };
 
-// What one column block of k_fcs leaves for the next step: its best entering column as the step it has just prepared
-// leaves the tableau (score by devex), with everything the next kernel needs of that column should it win
-// (reduced cost, weight, bounds and status of its variable).  The column itself and its ratio test are in spcol / spr.
-struct SpecPart {
-  double score;
-  int q, sdir;
-  double dq, wq, lbq, ubq;
-  int fq, pad;
-};
-
 
 // Device-resident control block.  Kernels take only a pointer to it, so one launch
 // sequence serves every problem handle and pivots can be queued ahead of the host.
@@ -130,41 +120,43 @@ struct Ctl {
   double ch_elb[KCH], ch_eub[KCH]; // bounds of the entering variable (become row p's)
   double ch_llb[KCH], ch_lub[KCH]; // bounds of the leaving variable (become column q's)
   double *srowk[KCH], *colqk[KCH]; // scaled pivot row / pivot column of step l
-  // Speculative chained primal path (k_fcs / k_fbc2): ONE launch per step.  Every column block prices its own columns
-  // as the step it has just prepared leaves them and at once gathers its best column, carries it through the pending
-  // chain and runs the ratio test on it; the next launch reduces these candidates to the winner, whose leaving row is
-  // then already known.  Two sets of everything a step hands to the next, alternating with the step count
-  // (set read by step g of a chain = (curA + g) & 1).
-  SpecPart *sp[2]; // [ncb]
-  Cand *spr[2];    // [ncb * R] ratio-test partials of the candidates, one per row group
-  double *spcol[2]; // [ncb][m_cap+1] the candidate columns
-  double *drow[2]; // [ld] objective row
-  double *betak[2]; // [m_cap+1] basic values as of the step (column 0 carried through the pending chain)
+  // Chained primal path (k_pboot / k_pc / k_pr / k_fbc2): what the device decides about the pending chain
   int pc_n;        // steps recorded in the pending chain (k_fbc2 applies them and resets it)
   int pc_epoch;    // chains applied so far + 1
   unsigned pc_arrive; // k_fbc2: workgroups that have finished (the last one commits the chain's bookkeeping)
   int ch_kind[KCH], ch_cnt[KCH], ch_ok[KCH]; // ST_PIVOT / ST_FLIP; pivots among steps 0..l; == pc_epoch once step l is recorded
+  int ch_okc[KCH];  // == pc_epoch once k_pc has chosen step l's entering column
+  int hd_q[KCH], hd_sdir[KCH], hd_fq[KCH]; // the entering column of step l as k_pc found it: column, direction, status,
+  double hd_dq[KCH], hd_wq[KCH], hd_lbq[KCH], hd_ubq[KCH]; // reduced cost, weight, bounds
   double ch_delta[KCH]; // bound flips: the entering variable's move
   unsigned long long *dbg; // diagnostic phase stamps of k_fcs (MVX_FCS_DBG=1), nullptr otherwise
 };
 
-// What the kernels of the speculative chained primal path need that the host knows (pointers, geometry, tolerances):
-// passed by value, so that no dependent load stands between a launch and its data; what the device decides -- the
-// chain, the counters, the verdicts -- stays in the control block.
-struct FcsArgs {
+// What the kernels of the chained primal path (k_pboot / k_pc / k_pr / k_fbc2) need that the host knows -- pointers,
+// geometry, tolerances: passed by value, so that no dependent load stands between a launch and its data; what the
+// device decides -- the chain, the counters, the verdicts -- stays in the control block.
+// State that a step changes is kept in two sets that alternate with the step index (a launch never writes what a
+// workgroup of the same launch may still read); the chain starts from the handle's own arrays ("base").
+struct ChainArgs {
   Ctl *c;
   double *T;
-  double *blb, *bub, *nlb, *nub;
+  double *blb, *bub, *nlb, *nub; // base: the handle's own arrays (the bulk launch's commit brings them up to date)
   int *nflag;
-  SpecPart *sp[2];
-  Cand *spr[2];
-  double *spcol[2], *drow[2], *pw[2], *betak[2];
+  double *pw[2];                 // base weights: both sets hold them between chains (the generic step reads pw[curA & 1])
+  double *betab;                 // base basic values: column 0, exported contiguously by k_pboot / k_fbc2
+  // column side, as of step g in set g & 1: objective row, devex weights, statuses and bounds of the non-basic variables
+  double *drowk[2], *pwk[2], *nlbk[2], *nubk[2];
+  int *nflagk[2];
+  // row side, as of step g in set g & 1: basic values and bounds of the basic variables
+  double *betak[2], *blbk[2], *bubk[2];
+  double *pp; // pricing partials of k_pr / k_pboot: 8 fields x ppstride (score, q, sdir, d_q, w_q, lb_q, ub_q, flag_q)
+  double *rp; // ratio-test partials of k_pc: 4 fields x rpstride (step, |a|, row, to_upper)
+  size_t ppstride, rpstride;
   double *srow0, *colq0; // scaled pivot rows / pivot columns of the chain's steps, `sstride` / `cstride` doubles apart
   size_t sstride, cstride;
-  int m, n, ld, mcap1;
+  int m, n, ld, mcap1, ncb, nrb; // ncb column blocks (k_pr), nrb row blocks (k_pc)
   double tol_dj, tol_piv, tol_bnd, sgn;
   int stall_limit;
-  int ncb, R; // column blocks / row groups of k_fcs's grid
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots

@@ -1,4 +1,5 @@
-"""Phase stamps of k_fcs (lead workgroup), per chain position: MVX_FCS_DBG=1 python scripts/fcsdbg.py [m n pivots]"""
+"""Phase stamps of the chained path's step kernels (lead workgroup), per chain position:
+python scripts/fcsdbg.py [m n pivots]   (sets MVX_FCS_DBG=1)"""
 import ctypes as C, os, sys
 os.environ["MVX_FCS_DBG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,15 +13,15 @@ P.load_dense(A, b, c)
 P.simplex(it_lim=piv)
 lib = mvolps_amd.load_library()
 lib.mvx_fcs_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
-buf = (C.c_ulonglong * (34 * 8))()
+buf = (C.c_ulonglong * (32 * 16))()
 rows = lib.mvx_fcs_debug_stamps(buf)
-names = ["entry", "to winner", "L2 loads", "row phase", "local best", "fresh col", "own step", "ratio/out"]
-print("pos  " + " ".join("%11s" % x for x in names) + "   total_us")
-for g in list(range(rows - 1)) + [rows - 1]:
-    st = [buf[g * 8 + k] for k in range(8)]
-    if st[0] == 0:
+print("k_pc: entry->winner, gather issue, carried state, column carry, ratio+reduce, stores | k_pr: entry->row, L2 issue, divs, row carry+step, price+reduce, stores  (us)")
+for g in range(rows):
+    a = [buf[g * 16 + k] for k in range(6)]
+    r = [buf[g * 16 + 8 + k] for k in range(6)]
+    if a[0] == 0:
         continue
-    d = [(st[k + 1] - st[k]) / 100.0 if st[k + 1] and st[k] else 0.0 for k in range(7)]
-    print("%-4s " % ("boot" if g == rows - 1 else g) + " ".join("%11.2f" % x for x in [0.0] + d) + "   %8.2f" % ((max(st) - st[0]) / 100.0))
-
-print("blocks: kept candidate %d, fresh column %d, no candidate %d" % (buf[33 * 8], buf[33 * 8 + 1], buf[33 * 8 + 2]))
+    da = [(a[k + 1] - a[k]) / 100.0 for k in range(5)]
+    dr = [(r[k + 1] - r[k]) / 100.0 for k in range(5)]
+    print("%2d  pc %s = %6.2f | pr %s = %6.2f | pc->pr gap %6.2f" % (g, " ".join("%5.2f" % x for x in da), (a[5] - a[0]) / 100.0,
+                                                                  " ".join("%5.2f" % x for x in dr), (r[5] - r[0]) / 100.0, (r[0] - a[5]) / 100.0))
