@@ -52,7 +52,8 @@ int chain_nrb(int m);
 void launch_pboot(const ChainArgs &, hipStream_t);
 void launch_pstep(const ChainArgs &, int g, hipStream_t);
 void launch_pc(const ChainArgs &, int g, hipStream_t);
-void launch_fbc2(const ChainArgs &, hipStream_t);
+void launch_fbc3(const ChainArgs &, hipStream_t);
+void launch_fpatch(const ChainArgs &, int steps, hipStream_t);
 void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
@@ -103,6 +104,7 @@ struct SolveCtx {
   double *d_drowk[2] = {}, *d_pwk[2] = {}, *d_nlbk[2] = {}, *d_nubk[2] = {}, *d_betak[2] = {}, *d_blbk[2] = {}, *d_bubk[2] = {};
   int *d_nflagk[2] = {};
   double *d_betab = nullptr, *d_ppart = nullptr, *d_rpart = nullptr;
+  double *d_zeros = nullptr; // chained primal path: zeros (bound-flip operands of the bulk pass)
   size_t pp_stride = 0, rp_stride = 0;
   size_t sk_stride = 0, ck_stride = 0; // doubles between the chain's consecutive scaled pivot rows / pivot columns
   Cand *d_rpc = nullptr;
@@ -289,6 +291,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   }
   const size_t pps = align_up((size_t)chain_ncb(l) + 1, 32), rps = align_up((size_t)chain_nrb(mc) + 1, 32);
   const size_t o_betab = carve((size_t)(mc + 1) * 8), o_ppart = carve(8 * pps * 8), o_rpart = carve(4 * rps * 8);
+  const size_t o_zeros = carve((size_t)std::max(l, mc + 1) * 8 + 256);
   HIPCHECK(hipMalloc(&sc.scratch, off));
   HIPCHECK(hipMemsetAsync(sc.scratch, 0, off, sc.stream));
   unsigned char *b = (unsigned char *)sc.scratch;
@@ -332,6 +335,7 @@ static void ensure_scratch(SolveCtx &sc, int m_cap, int ld) {
   sc.d_betab = (double *)(b + o_betab);
   sc.d_ppart = (double *)(b + o_ppart);
   sc.d_rpart = (double *)(b + o_rpart);
+  sc.d_zeros = (double *)(b + o_zeros);
   sc.pp_stride = pps;
   sc.rp_stride = rps;
   sc.sk_stride = (o_sk[1] - o_sk[0]) / 8;
@@ -947,6 +951,7 @@ static void job_begin(Context &c, SolveJob &J) {
     a.ncb = chain_ncb(P->n); a.nrb = chain_nrb(P->m);
     a.tol_dj = h->tol_dj; a.tol_piv = h->tol_piv; a.tol_bnd = h->tol_bnd; a.sgn = h->sgn;
     a.stall_limit = h->stall_limit;
+    a.zeros = sc.d_zeros;
   }
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   J.chain = J.chain0 = h->chain_max;
@@ -1035,7 +1040,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
         if (J.profiled) J.ev_used += 2;
         if (depth > 0) {
           // chained path: k_pboot once, then per chain of up to `kc` steps two small launches per step (k_pc / k_pr)
-          // and one bulk launch (k_fbc2), so `depth` pivots take depth / kc passes over the tableau when every chain
+          // and one bulk launch (k_fbc3), so `depth` pivots take depth / kc passes over the tableau when every chain
           // fills (a chain that ends early leaves pivots for the next batch)
           launch_pboot(J.cargs, sc.stream);
           const int kc = std::max(1, J.chain);
@@ -1043,7 +1048,8 @@ static void job_enqueue(Context &c, SolveJob &J) {
             const int steps = std::min(kc, left); // the last pass of a limited run chains only what the limit leaves
             for (int t = 0; t < steps; t++) launch_pstep(J.cargs, t, sc.stream);
             ev();
-            launch_fbc2(J.cargs, sc.stream);
+            launch_fbc3(J.cargs, sc.stream);
+            launch_fpatch(J.cargs, steps, sc.stream);
             ev();
             left -= steps;
           }

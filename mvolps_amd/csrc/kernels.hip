@@ -1574,7 +1574,8 @@ __global__ __launch_bounds__(256) void k_fb(Ctl *c) {
 //                flip of the entering variable: a step of its own kind); row p_g carried through the chain -> scaled
 //                pivot row; objective row, devex weights, statuses and bounds of the columns as the step leaves them;
 //                pricing partials for step g+1
-//   k_fbc2       the bulk pass
+//   k_fbc3       the bulk pass: the plain multiply-adds of every step
+//   k_fpatch     the chain's pivot rows, pivot columns and column 0; the chain's bookkeeping
 // What two rounds of in-kernel stamps taught (scripts/fcsdbg.py): a step is a chain of dependent
 // memory round trips, so (1) pointers, geometry and tolerances come by value (ChainArgs): every load whose address is
 // known on entry is requested on entry; (2) loads are unconditional -- indices are clamped, results masked -- because a
@@ -1794,6 +1795,7 @@ __global__ __launch_bounds__(256) void k_pc(const ChainArgs A, int g) {
     }
   }
   if (done != D_RUN || fstate != F_RUN) return;
+  if (lead && g == 0) c->pc_n = 0; // a new chain: nothing recorded yet (the bulk pass and k_fpatch apply pc_n steps)
   if (g > 0 && okprev != epoch) return; // the chain ended before this step
   Cand key{m_q ? m_sc : 0.0, 0.0, m_q, lane};
   key = wave_bcast_best<0>(key);
@@ -2065,13 +2067,94 @@ __global__ __launch_bounds__(256) void k_pr(const ChainArgs A, int g) {
 #undef PR_STAMP
 }
 
+// The chain's bookkeeping (one workgroup, every thread calls): the basis swaps of the chain in order -- a swap exchanges
+// (variable, bounds) between row p_t and column q_t.  The bounds need no exchange: the selection recorded what enters
+// row p_t (ch_elb / ch_eub) and what comes to sit in column q_t (ch_llb / ch_lub), so the last step that touches a row
+// or a column writes them; the variable numbers go through the swaps in LDS (one lane, no memory round trip per step),
+// lane t holding step t.  Nothing the bulk pass or k_fpatch reads is touched (they read the chain's record and pc_n).
+__device__ void chain_commit(const ChainArgs &A, Ctl *c, int nch) {
+  __shared__ int s_cp[KCH], s_cq[KCH], s_ck[KCH], s_rf[KCH], s_cf[KCH], s_R[KCH], s_C[KCH];
+  const int t = TIDX;
+  const bool on = (t < nch);
+  int kind = 0, p = 0, q = 0;
+  if (on) {
+    kind = c->ch_kind[t];
+    p = c->ch_p[t];
+    q = c->ch_q[t];
+    s_ck[t] = kind;
+    s_cp[t] = p;
+    s_cq[t] = q;
+    s_R[t] = (kind == ST_PIVOT) ? c->bvar[p] : 0;
+    s_C[t] = (kind == ST_PIVOT) ? c->nvar[q] : 0;
+  }
+  __syncthreads();
+  bool lastrow = true, lastcol = true, lastflag = true;
+  if (on) {
+    int rf = t, cf = t;
+    for (int u = t - 1; u >= 0; u--) {
+      if (s_ck[u] != ST_PIVOT) continue;
+      if (s_cp[u] == p) rf = u;
+      if (s_cq[u] == q) cf = u;
+    }
+    s_rf[t] = rf;
+    s_cf[t] = cf;
+    for (int u = t + 1; u < nch; u++) {
+      if (s_cq[u] == q) lastflag = false;
+      if (s_ck[u] != ST_PIVOT) continue;
+      if (s_cp[u] == p) lastrow = false;
+      if (s_cq[u] == q) lastcol = false;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int u = 0; u < nch; u++) {
+      if (s_ck[u] != ST_PIVOT) continue;
+      const int a = s_rf[u], b = s_cf[u];
+      const int kv = s_R[a];
+      s_R[a] = s_C[b];
+      s_C[b] = kv;
+    }
+  }
+  __syncthreads();
+  if (on) {
+    if (kind == ST_PIVOT) {
+      if (lastrow) {
+        c->bvar[p] = s_R[s_rf[t]];
+        A.blb[p] = c->ch_elb[t];
+        A.bub[p] = c->ch_eub[t];
+      }
+      if (lastcol) {
+        c->nvar[q] = s_C[s_cf[t]];
+        A.nlb[q] = c->ch_llb[t];
+        A.nub[q] = c->ch_lub[t];
+      }
+    }
+    if (lastflag) A.nflag[q] = c->ch_lf[t];
+  }
+  if (t == 0) {
+    const int piv_n = c->ch_cnt[nch - 1];
+    c->it_cnt += piv_n;
+    c->n_flips += nch - piv_n;
+    c->n_bulk++;
+    if (c->budget > 0) c->budget -= piv_n;
+    c->stall = c->ch_stall[nch - 1];
+    c->pc_epoch++;
+  }
+}
+
 // The bulk pass of a chain.  Every entry is loaded once, goes through the chain's steps in registers and is stored
-// once.  What a step needs besides the entry -- the pivot-column entries of the tile's rows, the step's description --
-// is the same for every lane: it comes in through scalar loads (constant address space: nothing in this launch writes
-// it) and sits in SGPRs, so there is no LDS staging and no barrier.
+// once.  What a step needs besides the entry -- the pivot-column entries of the tile's rows -- is the same for every
+// lane: it comes in through scalar loads (constant address space: nothing in this launch writes it) and sits in SGPRs,
+// so there is no LDS staging and no barrier.  The loop body is 2 TR multiply-adds per lane and nothing else: a bound
+// flip runs them on zeros (fma(-0, 0, v) = v bit for bit), and the entries a step treats differently -- the pivot row
+// (becomes -s_j), the pivot column (c_i / piv), column 0 under a bound flip -- are not this kernel's business: what they
+// hold after their step does not depend on what they held before, so k_fpatch writes the chain's pivot rows, pivot
+// columns and column 0 afterwards from the chain's own data.  (With the exceptions inside this loop the compiler kept
+// two or three copies of the tile in registers and moved the tile between them every step: 210 VGPRs, 140 us for 16
+// steps; profiles/r03_*.)  Column 0 is never stored here: k_fpatch needs it as it was.
 typedef const double __attribute__((address_space(4))) *kconst_f64;
 template <int TR, int NT>
-__global__ __launch_bounds__(256) void k_fbc2(const ChainArgs A) {
+__global__ __launch_bounds__(256) void k_fbc3(const ChainArgs A) {
   Ctl *const c = A.c;
   if (c->done != D_RUN || c->fstate != F_RUN) return;
   const int nch = c->pc_n;
@@ -2080,104 +2163,120 @@ __global__ __launch_bounds__(256) void k_fbc2(const ChainArgs A) {
   const size_t ld = (size_t)A.ld;
   const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
   const int i0 = 1 + (int)blockIdx.y * TR;
-  const bool has0 = (j0 == 0);
   const int xf = nch & 1; // the set the chain's last step wrote
   if (j0 <= n) {
-    double *base = A.T + (size_t)i0 * ld + j0;
-    double2 v[TR];
+  double *base = A.T + (size_t)i0 * ld + j0;
+  double2 v[TR];
 #pragma unroll
-    for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
-    for (int l = 0; l < nch; l++) {
-      const kconst_f64 cq = (kconst_f64)(A.colq0 + (size_t)l * A.cstride + i0);
-      const int kind = c->ch_kind[l];
-      if (kind == ST_FLIP) { // only column 0 moves
-        if (has0) {
-          const double delta = c->ch_delta[l];
+  for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
+  unsigned flips = 0; // which steps are bound flips: known before the loop, so no step waits for its own description
+  for (int l = 0; l < nch; l++) flips |= (c->ch_kind[l] == ST_FLIP) ? (1u << l) : 0u;
+  const double *sp = A.srow0 + j0;
+  const double *zp = A.zeros + j0;
+  double2 s = *reinterpret_cast<const double2 *>((flips & 1u) ? zp : sp);
+  for (int l = 0; l < nch; l++) {
+    const bool flip = (flips >> l) & 1u;
+    const kconst_f64 cq = (kconst_f64)(flip ? A.zeros : A.colq0 + (size_t)l * A.cstride + i0);
+    // the next step's pair of the scaled pivot row is requested before this step's multiply-adds
+    const int ln = (l + 1 < nch) ? l + 1 : l;
+    const double2 sn = *reinterpret_cast<const double2 *>(((flips >> ln) & 1u) ? zp : sp + (size_t)ln * A.sstride);
 #pragma unroll
-          for (int r = 0; r < TR; r++) v[r].x = fma(cq[r], delta, v[r].x);
-        }
-        continue;
-      }
-      const double2 s = *reinterpret_cast<const double2 *>(A.srow0 + (size_t)l * A.sstride + j0);
-      const int p = c->ch_p[l], q = c->ch_q[l];
-      double ci[TR];
-#pragma unroll
-      for (int r = 0; r < TR; r++) ci[r] = cq[r];
-#pragma unroll
-      for (int r = 0; r < TR; r++) {
-        v[r].x = fma(-ci[r], s.x, v[r].x);
-        v[r].y = fma(-ci[r], s.y, v[r].y);
-      }
-      const bool q0 = (j0 == q), q1 = (j0 + 1 == q);
-      if (q0 || q1) {
-        const double piv = c->ch_piv[l];
-#pragma unroll
-        for (int r = 0; r < TR; r++) {
-          const double qv = xdiv(ci[r], piv);
-          if (q0) v[r].x = qv;
-          if (q1) v[r].y = qv;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (p >= i0 && p < i0 + TR) {
-        const double piv = c->ch_piv[l], xq = c->ch_xq[l];
-#pragma unroll
-        for (int r = 0; r < TR; r++) {
-          if (i0 + r == p) {
-            v[r].x = q0 ? xdiv(1.0, piv) : -s.x;
-            v[r].y = q1 ? xdiv(1.0, piv) : -s.y;
-            if (has0) v[r].x = xq - s.x;
-          }
-        }
-      }
+    for (int r = 0; r < TR; r++) {
+      // in place (an instruction with a tied operand)
+      const double ci = cq[r];
+      asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(v[r].x) : "s"(ci), "v"(s.x));
+      asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(v[r].y) : "s"(ci), "v"(s.y));
     }
+    s = sn;
+  }
+  if (j0 == 0) {
+#pragma unroll
+    for (int r = 0; r < TR; r++) base[(size_t)r * ld + 1] = v[r].y;
+  } else {
 #pragma unroll
     for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
-    if (has0) {
-#pragma unroll
-      for (int r = 0; r < TR; r++) A.betab[i0 + r] = v[r].x;
-    }
-    if (blockIdx.y == 0) { // the objective row and the weights live outside the row blocks: back to where the other paths read them
-      *reinterpret_cast<double2 *>(A.T + j0) = *reinterpret_cast<const double2 *>(A.drowk[xf] + j0);
-      const double2 w = *reinterpret_cast<const double2 *>(A.pwk[xf] + j0);
-      *reinterpret_cast<double2 *>(A.pw[0] + j0) = w;
-      *reinterpret_cast<double2 *>(A.pw[1] + j0) = w;
-    }
   }
-  // The chain's bookkeeping is committed by whichever workgroup finishes last: every other one has read what it needs
-  // of the control block by then.
-  if (NT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (TIDX == 0) {
-    const unsigned total = gridDim.x * gridDim.y;
-    const unsigned t = atomicAdd(&c->pc_arrive, 1u);
-    if (t == total - 1) {
-      for (int l = 0; l < nch; l++) { // the basis swaps of the chain, in order
-        const int q = c->ch_q[l];
-        if (c->ch_kind[l] == ST_FLIP) {
-          A.nflag[q] = c->ch_lf[l];
-          continue;
+  if (blockIdx.y == 0) { // the objective row and the weights live outside the row blocks: back to where the other paths read them
+    *reinterpret_cast<double2 *>(A.T + j0) = *reinterpret_cast<const double2 *>(A.drowk[xf] + j0);
+    const double2 w = *reinterpret_cast<const double2 *>(A.pwk[xf] + j0);
+    *reinterpret_cast<double2 *>(A.pw[0] + j0) = w;
+    *reinterpret_cast<double2 *>(A.pw[1] + j0) = w;
+  }
+  }
+  // the first workgroup to be dispatched also commits the chain's bookkeeping, beside the rest of the pass
+  if (blockIdx.x == 0 && blockIdx.y == 0) chain_commit(A, c, nch);
+}
+
+// After the bulk pass: the chain's pivot rows and pivot columns (what they hold after their own step does not depend
+// on what they held before it: written from the chain's data and carried through the steps that follow), column 0 (from
+// its old values, which the bulk pass leaves alone: bound flips move it) with its contiguous copy.  Jobs (blockIdx.y): 0 .. K-1 the pivot row of step y, K .. 2K-1
+// the pivot column of step y - K, 2K column 0.  An entry that two jobs cover gets the same value from both.  The rules
+// of the bulk update in full: the pivot row becomes -s_j (1/piv at the pivot, x_q - s_0 in column 0), the pivot column
+// c_i / piv, a bound flip moves column 0 only, everything else fma(-c_i, s_j, v).  Every operand of every step is
+// requested up front (the steps' descriptions and the operand that is the same for the whole job into LDS, the other
+// one into registers): two memory round trips per launch, not two per step.
+__global__ __launch_bounds__(256) void k_fpatch(const ChainArgs A, int kmax) {
+  __shared__ int s_kind[KCH], s_p[KCH], s_q[KCH];
+  __shared__ double s_piv[KCH], s_ip[KCH], s_xq[KCH], s_delta[KCH], s_u[KCH];
+  Ctl *const c = A.c;
+  if (c->done != D_RUN || c->fstate != F_RUN) return;
+  const int nch = c->pc_n;
+  if (nch == 0) return;
+  const int m = A.m, n = A.n;
+  const size_t ld = (size_t)A.ld;
+  const int job = (int)blockIdx.y, x = (int)blockIdx.x * 256 + TIDX;
+  // job kind 0: row p_l (x = column), 1: column q_l (x = row), 2: column 0 (x = row)
+  const int jk = (job < kmax) ? 0 : (job < 2 * kmax) ? 1 : 2;
+  const int l = (jk == 0) ? job : (jk == 1) ? job - kmax : -1;
+  bool live = (jk == 2) || (l < nch && c->ch_kind[l < nch ? l : 0] == ST_PIVOT);
+  const int span = (jk == 0) ? n : (jk == 1) ? m : A.mcap1 - 1;
+  if ((int)blockIdx.x * 256 > span) live = false; // nothing of this job in this block
+  if (live) {
+    const int lp = (l >= 0) ? c->ch_p[l] : 0, lq = (l >= 0) ? c->ch_q[l] : 0;
+    if (TIDX < KCH) {
+      const int t = (TIDX < nch) ? TIDX : nch - 1;
+      const int kind = c->ch_kind[t];
+      const double piv = c->ch_piv[t];
+      s_kind[TIDX] = kind;
+      s_p[TIDX] = c->ch_p[t];
+      s_q[TIDX] = c->ch_q[t];
+      s_piv[TIDX] = piv;
+      s_ip[TIDX] = (kind == ST_PIVOT) ? xdiv(1.0, piv) : 0.0;
+      s_xq[TIDX] = c->ch_xq[t];
+      s_delta[TIDX] = c->ch_delta[t];
+      // the operand every entry of the job shares: row job c_t[p_l]; column job s_t[q_l]; column 0 s_t[0]
+      s_u[TIDX] = (jk == 0) ? A.colq0[(size_t)t * A.cstride + lp] : A.srow0[(size_t)t * A.sstride + (jk == 1 ? lq : 0)];
+    }
+    const int xc = (x >= 1 && x <= span) ? x : 1;
+    double op[KCH]; // the other operand, per entry: row job s_t[x]; column jobs c_t[x]
+#pragma unroll
+    for (int t = 0; t < KCH; t++) {
+      const int tc = (t < nch) ? t : nch - 1;
+      op[t] = (jk == 0) ? A.srow0[(size_t)tc * A.sstride + xc] : A.colq0[(size_t)tc * A.cstride + xc];
+    }
+    double *dst = (jk == 0) ? A.T + (size_t)lp * ld + xc : A.T + (size_t)xc * ld + (jk == 1 ? lq : 0);
+    double val = (jk == 2) ? *dst : 0.0;
+    __syncthreads();
+    const int i = (jk == 0) ? lp : xc, j = (jk == 0) ? xc : (jk == 1) ? lq : 0;
+    const int l0 = (jk == 2) ? 0 : l;
+#pragma unroll
+    for (int t = 0; t < KCH; t++) {
+      if (t >= l0 && t < nch) {
+        const double ci = (jk == 0) ? s_u[t] : op[t], sj = (jk == 0) ? op[t] : s_u[t];
+        if (s_kind[t] == ST_FLIP) {
+          if (j == 0) val = fma(ci, s_delta[t], val);
+        } else if (i == s_p[t]) {
+          val = (j == s_q[t]) ? s_ip[t] : (j == 0) ? s_xq[t] - sj : -sj;
+        } else if (j == s_q[t]) {
+          val = xdiv(ci, s_piv[t]);
+        } else {
+          val = fma(-ci, sj, val);
         }
-        const int p = c->ch_p[l];
-        const int kv = c->bvar[p];
-        const double klb = A.blb[p], kub = A.bub[p];
-        c->bvar[p] = c->nvar[q];
-        A.blb[p] = A.nlb[q];
-        A.bub[p] = A.nub[q];
-        c->nvar[q] = kv;
-        A.nlb[q] = klb;
-        A.nub[q] = kub;
-        A.nflag[q] = c->ch_lf[l];
       }
-      const int piv_n = c->ch_cnt[nch - 1];
-      c->it_cnt += piv_n;
-      c->n_flips += nch - piv_n;
-      c->n_bulk++;
-      if (c->budget > 0) c->budget -= piv_n;
-      c->stall = c->ch_stall[nch - 1];
-      c->pc_n = 0;
-      c->pc_epoch++;
-      c->pc_arrive = 0;
+    }
+    if (x >= 1 && x <= span) {
+      if (jk != 2 || x <= m) *dst = val; // spare rows behind row m: their pivot-column entries are zero, the value stays
+      if (jk == 2) A.betab[x] = val;
     }
   }
 }
@@ -3013,7 +3112,11 @@ void launch_pstep(const ChainArgs &a, int g, hipStream_t s) {
   hipLaunchKernelGGL(k_pr, dim3(a.ncb), dim3(256), 0, s, a, g);
 }
 void launch_pc(const ChainArgs &a, int g, hipStream_t s) { hipLaunchKernelGGL(k_pc, dim3(a.nrb), dim3(256), 0, s, a, g); }
-void launch_fbc2(const ChainArgs &a, hipStream_t s) {
+void launch_fpatch(const ChainArgs &a, int steps, hipStream_t s) {
+  const int span = a.mcap1 > a.n + 1 ? a.mcap1 : a.n + 1;
+  hipLaunchKernelGGL(k_fpatch, dim3((span + 255) / 256, 2 * steps + 1), dim3(256), 0, s, a, steps);
+}
+void launch_fbc3(const ChainArgs &a, hipStream_t s) {
   const int m = a.m, n = a.n;
   const int pairs = (n + 2) / 2;
   int tr = pick_tr(m, n);
@@ -3021,7 +3124,7 @@ void launch_fbc2(const ChainArgs &a, hipStream_t s) {
   const int nt = pick_nt(m, n);
   dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
 #define FBC2_CASE(TR_, NT_) \
-  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fbc2<TR_, NT_>), grid, dim3(256), 0, s, a); return; }
+  if (tr == TR_ && nt == NT_) { hipLaunchKernelGGL((k_fbc3<TR_, NT_>), grid, dim3(256), 0, s, a); return; }
   FBC2_CASE(16, 0) FBC2_CASE(16, 1) FBC2_CASE(16, 2) FBC2_CASE(8, 0) FBC2_CASE(8, 1) FBC2_CASE(8, 2) FBC2_CASE(4, 0) FBC2_CASE(4, 1) FBC2_CASE(4, 2)
 #undef FBC2_CASE
   std::abort(); // unreachable

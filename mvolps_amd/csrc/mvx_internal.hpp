@@ -26,7 +26,7 @@ constexpr double DEGEN_TOL = 1e-9; // a step / dual ratio no longer than this co
 constexpr double PERT_EPS = 1e-6; // relative size of the anti-stalling bound perturbation (oracle: PERT_EPS)
 constexpr size_t NT_THRESHOLD_BYTES = (size_t)320 << 20; // tableaux larger than this stream with non-temporal access (pick_nt)
 constexpr size_t WT_MIN_BYTES = (size_t)96 << 20, WT_MAX_BYTES = (size_t)272 << 20; // write-through stores in this band (pick_nt)
-constexpr int KCH = 32;          // most steps one bulk launch of the chained primal path applies (k_fcs / k_fbc2)
+constexpr int KCH = 32;          // most steps one bulk launch of the chained primal path applies (k_fcs / k_fbc3)
 constexpr int DCH_MAX = 8;  // most dual pivots one k_update applies (dual_chain)
 constexpr int DA_THREADS = 1024; // k_dboot / k_da workgroup size: the O(m) leaving-row pass is redundant per block
 constexpr int MAX_EDITS = 8;      // pending bound edits a control block carries (more are flushed by launches)
@@ -120,19 +120,20 @@ struct Ctl {
   double ch_elb[KCH], ch_eub[KCH]; // bounds of the entering variable (become row p's)
   double ch_llb[KCH], ch_lub[KCH]; // bounds of the leaving variable (become column q's)
   double *srowk[KCH], *colqk[KCH]; // scaled pivot row / pivot column of step l
-  // Chained primal path (k_pboot / k_pc / k_pr / k_fbc2): what the device decides about the pending chain
-  int pc_n;        // steps recorded in the pending chain (k_fbc2 applies them and resets it)
+  // Chained primal path (k_pboot / k_pc / k_pr / k_fbc3): what the device decides about the pending chain
+  int pc_n;        // steps recorded in the pending chain (k_fbc3 applies them and resets it)
   int pc_epoch;    // chains applied so far + 1
-  unsigned pc_arrive; // k_fbc2: workgroups that have finished (the last one commits the chain's bookkeeping)
+  unsigned pc_arrive; // k_fbc3: workgroups that have finished (the last one commits the chain's bookkeeping)
   int ch_kind[KCH], ch_cnt[KCH], ch_ok[KCH]; // ST_PIVOT / ST_FLIP; pivots among steps 0..l; == pc_epoch once step l is recorded
   int ch_okc[KCH];  // == pc_epoch once k_pc has chosen step l's entering column
   int hd_q[KCH], hd_sdir[KCH], hd_fq[KCH]; // the entering column of step l as k_pc found it: column, direction, status,
   double hd_dq[KCH], hd_wq[KCH], hd_lbq[KCH], hd_ubq[KCH]; // reduced cost, weight, bounds
   double ch_delta[KCH]; // bound flips: the entering variable's move
+  int cl_abort;         // k_chain gave up waiting for its peer workgroups: the chain was dropped, nothing was changed
   unsigned long long *dbg; // diagnostic phase stamps of k_fcs (MVX_FCS_DBG=1), nullptr otherwise
 };
 
-// What the kernels of the chained primal path (k_pboot / k_pc / k_pr / k_fbc2) need that the host knows -- pointers,
+// What the kernels of the chained primal path (k_pboot / k_pc / k_pr / k_fbc3) need that the host knows -- pointers,
 // geometry, tolerances: passed by value, so that no dependent load stands between a launch and its data; what the
 // device decides -- the chain, the counters, the verdicts -- stays in the control block.
 // State that a step changes is kept in two sets that alternate with the step index (a launch never writes what a
@@ -143,7 +144,7 @@ struct ChainArgs {
   double *blb, *bub, *nlb, *nub; // base: the handle's own arrays (the bulk launch's commit brings them up to date)
   int *nflag;
   double *pw[2];                 // base weights: both sets hold them between chains (the generic step reads pw[curA & 1])
-  double *betab;                 // base basic values: column 0, exported contiguously by k_pboot / k_fbc2
+  double *betab;                 // base basic values: column 0, exported contiguously by k_pboot / k_fbc3
   // column side, as of step g in set g & 1: objective row, devex weights, statuses and bounds of the non-basic variables
   double *drowk[2], *pwk[2], *nlbk[2], *nubk[2];
   int *nflagk[2];
@@ -157,6 +158,13 @@ struct ChainArgs {
   int m, n, ld, mcap1, ncb, nrb; // ncb column blocks (k_pr), nrb row blocks (k_pc)
   double tol_dj, tol_piv, tol_bnd, sgn;
   int stall_limit;
+  const double *zeros; // max(ld, m_cap + 1) zeros: the operands of a bound flip in the bulk pass
+  // one-XCD cluster selection (k_chain): exchange area, tags, participants, steps this launch may take
+  unsigned *xg;
+  int xg_bytes;
+  unsigned tagbase;
+  int nw, kmax;
+  int *xabort;
 };
 
 // Work queue of a batched solve (mvx_simplex_batch): the host uploads one control block per handle (`jobs`), the slots
