@@ -201,8 +201,14 @@ double mvx_row_residual(const mvx_prob *P);
    identical either way.  mvx_persist_stats: launches made / launches that aborted and were redone by the two-kernel path */
 void mvx_set_persist(int mode);
 /* Pivots one pass over the tableau applies on the fused primal path (the chained selection):
-   0 = by tableau size (default), 1 = one pivot per pass, 2..16 = chains of that length.  Results do not depend on it. */
+   0 = by tableau size (default), 1 = one pivot per pass, 2..32 = chains of that length.  Results do not depend on it. */
 void mvx_set_chain(int len);
+/* Who chooses the steps of a chain: 1 (default) one launch per chain -- up to 32 workgroups that stay resident and
+   exchange their candidates through the L2 of the XCD they share (k_chain); 0 two launches per step (k_pc / k_pr), which
+   also take over by themselves if a cluster launch ever gives up waiting for a peer.  Results do not depend on it.
+   mvx_cluster_stats: cluster launches made / launches that gave up */
+void mvx_set_cluster(int on);
+void mvx_cluster_stats(long long *launches, long long *aborts);
 /* the same for the dual simplex steps of the generic path (every warm-started B&B child): 0 = default (8 for launches
    shared by 32 or more node LPs and for tableaux of 16 MB and more, else 4), 1 = off, 2..8 = dual pivots one update
    pass applies */

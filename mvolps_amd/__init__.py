@@ -25,6 +25,8 @@ _EXTRA = {
     "set_batch_slots": (None, [C.c_int]),
     "set_persist": (None, [C.c_int]),
     "set_chain": (None, [C.c_int]),
+    "set_cluster": (None, [C.c_int]),
+    "cluster_stats": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "set_dual_chain": (None, [C.c_int]),
     "set_refresh": (None, [C.c_int, C.c_double]),
     "get_refresh_cnt": (C.c_int, [C.c_void_p]),

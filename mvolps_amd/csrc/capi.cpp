@@ -455,6 +455,8 @@ int mvx_get_refresh_cnt(const mvx_prob *P) { return P->refresh_cnt; }
 double mvx_row_residual(const mvx_prob *P) { return mvx::row_residual(P); }
 void mvx_set_persist(int mode) { mvx::set_persist(mode); }
 void mvx_set_chain(int len) { mvx::set_chain(len); }
+void mvx_set_cluster(int on) { mvx::set_cluster(on); }
+void mvx_cluster_stats(long long *launches, long long *aborts) { mvx::cluster_stats(launches, aborts); }
 void mvx_set_dual_chain(int len) { mvx::set_dual_chain(len); }
 void mvx_persist_stats(long long *launches, long long *aborts) { mvx::persist_stats(launches, aborts); }
 void mvx_persist_cycles(unsigned long long *out5) { mvx::persist_cycles(out5); }

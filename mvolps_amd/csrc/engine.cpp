@@ -54,6 +54,9 @@ void launch_pstep(const ChainArgs &, int g, hipStream_t);
 void launch_pc(const ChainArgs &, int g, hipStream_t);
 void launch_fbc3(const ChainArgs &, hipStream_t);
 void launch_fpatch(const ChainArgs &, int steps, hipStream_t);
+int launch_chain(const ChainArgs &, hipStream_t);
+int chain_cluster_nw(int m, int n);
+int chain_cluster_kmax(int m, int n);
 void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
@@ -85,6 +88,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // ------------------------------------------------------------------------------ context
 // One solve context = one HIP stream with its own control block, scratch and staging.  The main
 // context serves every single-handle call; mvx_simplex_batch has its own (BatchCtx below).
+constexpr size_t XG_BYTES = 4 * 8 * 64 * 16; // k_chain's exchange area: 4 regions x 8 fields x 64 records x 16 bytes
 struct SolveCtx {
   hipStream_t stream = nullptr;
   Ctl *d_ctl = nullptr;
@@ -105,6 +109,10 @@ struct SolveCtx {
   int *d_nflagk[2] = {};
   double *d_betab = nullptr, *d_ppart = nullptr, *d_rpart = nullptr;
   double *d_zeros = nullptr; // chained primal path: zeros (bound-flip operands of the bulk pass)
+  // cluster selection (k_chain): exchange area, abort flag, tag of the next launch's first exchange
+  unsigned *d_xg = nullptr;
+  int *d_xabort = nullptr;
+  unsigned xtag = 0;
   size_t pp_stride = 0, rp_stride = 0;
   size_t sk_stride = 0, ck_stride = 0; // doubles between the chain's consecutive scaled pivot rows / pivot columns
   Cand *d_rpc = nullptr;
@@ -197,6 +205,9 @@ static void init_solve_ctx(SolveCtx &sc) {
   HIPCHECK(hipHostMalloc((void **)&sc.h_ctl, sizeof(Ctl)));
   HIPCHECK(hipEventCreate(&sc.ev_a));
   HIPCHECK(hipEventCreate(&sc.ev_b));
+  HIPCHECK(hipMalloc((void **)&sc.d_xg, XG_BYTES + 256));
+  HIPCHECK(hipMemset(sc.d_xg, 0, XG_BYTES + 256));
+  sc.d_xabort = (int *)((unsigned char *)sc.d_xg + XG_BYTES);
 }
 
 int take_last_error() { return g_last_error.exchange(0); }
@@ -576,6 +587,22 @@ static inline void var_bounds(const mvx_prob *P, int k, double *lb, double *ub) 
   }
 }
 
+// Cluster selection (k_chain): one launch chooses a whole chain.  MVX_CLUSTER=0 keeps the two launches per step
+// (k_pc / k_pr), which also take over for the rest of the process when a cluster launch ever gives up waiting for its
+// peer workgroups (cl_abort), and serve the geometries k_chain does not cover (more than 16384 rows or columns).
+static std::atomic<int> g_cluster{-1};
+static std::atomic<bool> g_cluster_broken{false};
+static std::atomic<long long> g_cluster_launches{0}, g_cluster_aborts{0};
+static bool cluster_wanted() {
+  int v = g_cluster.load();
+  if (v < 0) {
+    const char *e = std::getenv("MVX_CLUSTER");
+    v = e ? (std::atoi(e) != 0) : 1;
+    g_cluster.store(v);
+  }
+  return v != 0 && !g_cluster_broken.load();
+}
+
 // Steps per bulk launch of the chained primal path.  A step costs one small launch (k_fcs), a pass over the tableau
 // costs its bytes: chains pay at every size, the longer the pass the longer the chain (scripts/chainsweep.py).
 // MVX_CHAIN=1 turns the chaining off, 2..KCH fixes the length.
@@ -587,6 +614,7 @@ static int chain_length(const mvx_prob *P) {
   }
   if (g_chain > 0) return g_chain;
   const size_t bytes = (size_t)(P->m + 1) * (size_t)P->ld * 8;
+  if (cluster_wanted() && chain_cluster_kmax(P->m, P->n) > 0) return bytes < ((size_t)24 << 20) ? 16 : 32; // a step costs no launch there
   if (bytes < ((size_t)24 << 20)) return 8;
   return 16;
 }
@@ -885,6 +913,7 @@ struct SolveJob {
   bool persist_queued = false; // this batch of launches contains a k_persist launch (its abort flag is copied back)
   int seen_steps = 0, seen_pivots = 0, seen_bulk = 0;
   int chain = 1, chain0 = 1; // pivots per bulk launch the next batch is queued for / the size rule's choice
+  bool cluster = false;      // the chains of this solve are chosen by k_chain (one launch) instead of k_pc / k_pr per step
   ChainArgs cargs{};         // what the kernels of the chained primal path take by value
   size_t ev_used = 0;
   bool profiled = false;
@@ -952,7 +981,10 @@ static void job_begin(Context &c, SolveJob &J) {
     a.tol_dj = h->tol_dj; a.tol_piv = h->tol_piv; a.tol_bnd = h->tol_bnd; a.sgn = h->sgn;
     a.stall_limit = h->stall_limit;
     a.zeros = sc.d_zeros;
+    a.xg = sc.d_xg; a.xg_bytes = (int)XG_BYTES; a.xabort = sc.d_xabort;
+    a.nw = chain_cluster_nw(P->m, P->n); a.kmax = 0; a.tagbase = 0;
   }
+  J.cluster = cluster_wanted() && chain_cluster_kmax(P->m, P->n) > 0;
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   J.chain = J.chain0 = h->chain_max;
   J.try_dfused = P->hint_dual && dual_fused_worth_it(P);
@@ -1043,18 +1075,31 @@ static void job_enqueue(Context &c, SolveJob &J) {
           // and one bulk launch (k_fbc3), so `depth` pivots take depth / kc passes over the tableau when every chain
           // fills (a chain that ends early leaves pivots for the next batch)
           launch_pboot(J.cargs, sc.stream);
-          const int kc = std::max(1, J.chain);
+          const bool cl = J.cluster && !g_cluster_broken.load();
+          const int kc = cl ? std::max(1, std::min(J.chain0, chain_cluster_kmax(m, n))) : std::max(1, J.chain);
+          auto chain_launch = [&](int steps) { // k_chain: the whole selection of a chain of up to `steps` steps
+            J.cargs.kmax = steps;
+            J.cargs.tagbase = sc.xtag;
+            sc.xtag += 128;
+            if (launch_chain(J.cargs, sc.stream) != 0) g_cluster_broken.store(true);
+            g_cluster_launches++;
+          };
           for (int left = depth; left > 0;) {
             const int steps = std::min(kc, left); // the last pass of a limited run chains only what the limit leaves
-            for (int t = 0; t < steps; t++) launch_pstep(J.cargs, t, sc.stream);
+            if (cl) chain_launch(steps);
+            else
+              for (int t = 0; t < steps; t++) launch_pstep(J.cargs, t, sc.stream);
             ev();
             launch_fbc3(J.cargs, sc.stream);
             launch_fpatch(J.cargs, steps, sc.stream);
             ev();
             left -= steps;
           }
-          // a run that may end on the pivot limit: one more column phase, which finds the limit and reports it
-          if (J.parm.it_lim >= 0 && depth >= remaining) launch_pc(J.cargs, 0, sc.stream);
+          // a run that may end on the pivot limit: one more selection, which finds the limit and reports it
+          if (J.parm.it_lim >= 0 && depth >= remaining) {
+            if (cl) chain_launch(0);
+            else launch_pc(J.cargs, 0, sc.stream);
+          }
         }
         launch_select(sc.d_ctl, sc.stream);
         if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic], sc.stream));
@@ -1184,6 +1229,14 @@ static bool job_collect(Context &c, SolveJob &J) {
     const int steps_now = snap.n_bulk; // launches that stepped: one per pivot or flip, one per chain of pivots
     flush_update_events(c, std::min(J.ev_used, (size_t)2 * (size_t)(steps_now - J.seen_steps)));
     J.seen_steps = steps_now;
+  }
+  if (snap.cl_abort) {
+    // a cluster launch gave up waiting for its peers: it changed nothing, the rest of the batch returned at once and
+    // the closing generic step carried on; from here on the chains are chosen by k_pc / k_pr
+    g_cluster_broken.store(true);
+    g_cluster_aborts++;
+    std::fprintf(stderr, "mvx: cluster selection launch aborted (peer workgroups not reachable in time); using two launches per chained step from now on\n");
+    HIPCHECK(hipMemsetAsync(sc.d_xabort, 0, sizeof(int), sc.stream));
   }
   J.done = snap.done;
   {
@@ -2185,6 +2238,14 @@ void tuning(int tr, int hot, int nt) {
 
 void set_dual_chain(int len) { g_dchain = (len <= 0) ? 0 : std::min(DCH_MAX, len); } // <= 0: by batch width / size
 void set_chain(int len) { g_chain = (len <= 0) ? 0 : std::min(KCH, len); } // 0: by tableau size
+void set_cluster(int on) { // 0: k_pc / k_pr per step; 1: k_chain (default); also forgets an earlier abort
+  g_cluster.store(on != 0);
+  g_cluster_broken.store(false);
+}
+void cluster_stats(long long *launches, long long *aborts) {
+  *launches = g_cluster_launches.load();
+  *aborts = g_cluster_aborts.load();
+}
 void set_persist(int mode) {
   g_persist_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode); // 2: no size cap
   g_persist_broken = false;

@@ -42,6 +42,8 @@ void set_stall_limit(int limit);
 int fcs_debug_stamps(unsigned long long *out);
 void set_persist(int mode);
 void set_chain(int len);
+void set_cluster(int on);
+void cluster_stats(long long *launches, long long *aborts);
 void set_dual_chain(int len);
 void set_refresh(int check_every, double tol);
 double row_residual(const mvx_prob *P);

@@ -2067,6 +2067,523 @@ __global__ __launch_bounds__(256) void k_pr(const ChainArgs A, int g) {
 #undef PR_STAMP
 }
 
+// ================================================================= cluster selection (k_chain)
+// The whole selection of a chain in ONE launch.  k_pc / k_pr pay two launch boundaries per step, and behind each
+// boundary every first load goes to memory; here up to 32 workgroups stay resident for the chain, each owning 256 rows
+// and 256 columns (x RPT / CPT), and what a step changes besides the tableau lives in their registers: reduced costs,
+// devex weights, statuses and bounds of the columns; values and bounds of the rows.  The pivot columns / scaled pivot
+// rows of the earlier steps, which the carries need entry by entry, sit in LDS (one slot per thread and step).  A step
+// is two phases, each closed by an all-to-all exchange among the workgroups:
+//   column phase  gather column q (strided, from the tableau as it stands), carry it through the chain, ratio test
+//                 -> exchange: leaving row p with its pivot element, value and bounds
+//   row phase     load row p, carry it through the chain -> scaled pivot row; objective row, weights, statuses; pricing
+//                 -> exchange: entering column q of the NEXT step with its reduced cost, weight, bounds and its entry in
+//                 the scaled row just made
+// The exchange: every workgroup reduces its candidates (one barrier), publishes ONE record of eight self-tagged 16-byte
+// fields {lo, tag, hi, tag} with a single store instruction, and every wave sweeps all records (field-major: one
+// 16-byte load per field, lane = workgroup) until every tag is the exchange's own, then reduces them with shuffles:
+// no flag, no fence, no atomic; every reduction key is a strict total order, so all waves agree.  Placement: the launch
+// has 8 x NW workgroups and only those with blockIdx % 8 == 0 take part -- under the round-robin dispatch of this
+// device they share one XCD, whose L2 then serves the exchange (sc0 stores stay in that L2, sc1 loads bypass the L1:
+// 1.7 us per exchange against 3.3 us across the XCDs, scripts/probe/cluster_probe.hip).  Correctness does not rest on
+// that placement or on the workgroups being co-resident: a record that never shows up ends in a bounded wait, the
+// abort flag, and a launch that has changed nothing (the chain is recorded by workgroup 0 only at the very end); the
+// host then falls back on k_pc / k_pr.  What other workgroups read of a workgroup's stores (pivot columns, scaled rows
+// of earlier steps) they read with sc1 loads at least one full exchange after the store was issued in front of a sweep:
+// the sweep's loads are behind it in the wave's memory queue, so it has reached the L2 by then.
+constexpr int XNW = 64; // records per field row of the exchange area
+constexpr int XNF = 8;  // fields per record
+enum : int { XAUX_SC0 = 1, XAUX_SC1 = 16 };
+typedef unsigned xu4 __attribute__((ext_vector_type(4)));
+
+struct XCtx {
+  __amdgpu_buffer_rsrc_t rs;
+  int w, nw;
+  unsigned tag; // tag of the next exchange
+  int xno;      // exchanges so far
+  int *xabort;
+  bool dead;
+};
+
+__device__ __forceinline__ double ld_sc1(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Wave-wide maximum of a double through DPP row shifts / row broadcasts (six dependent steps of a few cycles each; the
+// shuffle form is six ds_bpermute round trips per value).  Every lane must be active.
+__device__ __forceinline__ double wave_max_f64(double v) {
+  const int ilo = __double2loint(-INFINITY), ihi = __double2hiint(-INFINITY);
+#define WMAX_STEP(CTRL, RMASK)                                                                            \
+  {                                                                                                       \
+    const int lo = __builtin_amdgcn_update_dpp(ilo, __double2loint(v), CTRL, RMASK, 0xf, false);          \
+    const int hi = __builtin_amdgcn_update_dpp(ihi, __double2hiint(v), CTRL, RMASK, 0xf, false);          \
+    v = fmax(v, __hiloint2double(hi, lo));                                                                \
+  }
+  WMAX_STEP(0x111, 0xf) // row_shr:1
+  WMAX_STEP(0x112, 0xf) // row_shr:2
+  WMAX_STEP(0x114, 0xf) // row_shr:4
+  WMAX_STEP(0x118, 0xf) // row_shr:8 -> lane 15 of every row holds the row's maximum
+  WMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+  WMAX_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef WMAX_STEP
+  return rl_d(v, 63);
+}
+// Wave-level arg-best, broadcast, with the lane that holds it.  The first key decides almost always: its maximum
+// (MODE 0) / minimum (MODE 1) by DPP, a ballot finds who holds it; only when several lanes tie on it (or none is
+// valid) the full keys go through the shuffle reduction.  Same winner as wave_bcast_best: the key is a total order.
+template <int MODE>
+__device__ __forceinline__ Cand wave_argbest(const Cand &x, int *who) {
+  const bool valid = (x.idx != 0);
+  const double key = valid ? (MODE == 0 ? x.k1 : -x.k1) : -INFINITY;
+  const double best = wave_max_f64(key);
+  const unsigned long long tied = __ballot(valid && key == best);
+  Cand r;
+  if (__builtin_popcountll(tied) == 1) {
+    const int l = (int)__builtin_ctzll(tied);
+    r.k1 = rl_d(x.k1, l);
+    r.k2 = rl_d(x.k2, l);
+    r.idx = rl_i(x.idx, l);
+    r.aux = rl_i(x.aux, l);
+    *who = l;
+    return r;
+  }
+  r = wave_bcast_best<MODE>(x);
+  const unsigned long long mk = __ballot(x.idx == r.idx && r.idx != 0);
+  *who = mk ? (int)__builtin_ctzll(mk) : 0;
+  return r;
+}
+
+// One exchange: `mine` is this thread's candidate with NP payload doubles; returns the winner among all workgroups and
+// its payload, the same in every thread of every workgroup.  One barrier.
+template <int MODE, int NP>
+__device__ __forceinline__ Cand xchg(XCtx &X, Cand mine, const double (&pin)[NP], double (&pout)[NP], Cand (*s_slots)[4], double (*s_pay)[4][5]) {
+  const int lane = TIDX & 63, wave = TIDX >> 6, b = X.xno & 1;
+  // workgroup level
+  int ol;
+  const Cand wb = wave_argbest<MODE>(mine, &ol);
+  if (lane == 0) s_slots[b][wave] = wb;
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    const double v = rl_d(pin[k], ol);
+    if (lane == 0) s_pay[b][wave][k] = v;
+  }
+  __syncthreads();
+  Cand bb = s_slots[b][0];
+  int bw = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++) {
+    const Cand y = s_slots[b][k];
+    if (cand_better<MODE>(y, bb)) {
+      bb = y;
+      bw = k;
+    }
+  }
+  const unsigned tag = X.tag;
+  const unsigned reg = (unsigned)(X.xno & 3) * (unsigned)(XNF * XNW * 16);
+  if (TIDX < 3 + NP) {
+    double v;
+    if (TIDX == 0) v = bb.k1;
+    else if (TIDX == 1) v = bb.k2;
+    else if (TIDX == 2) v = __hiloint2double(bb.aux, bb.idx);
+    else v = s_pay[b][bw][TIDX - 3];
+    const xu4 x = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(x, X.rs, reg + (unsigned)(TIDX * XNW + X.w) * 16, 0, XAUX_SC0);
+  }
+  // every wave sweeps: lane r < nw takes workgroup r's record
+  double rec[3 + NP];
+  const int lr = lane < X.nw ? lane : 0;
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int f = 0; f < 3 + NP; f++) {
+      const xu4 x = __builtin_amdgcn_raw_buffer_load_b128(X.rs, reg + (unsigned)(f * XNW + lr) * 16, 0, XAUX_SC1);
+      ok &= (x.y == tag) & (x.w == tag);
+      rec[f] = __hiloint2double((int)x.z, (int)x.x);
+    }
+    if (__all(ok)) break;
+    ++spins;
+    if ((spins & 255u) == 0) {
+      if (spins > 2000000u) __hip_atomic_store(X.xabort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spins > 2000000u || __hip_atomic_load(X.xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        X.dead = true;
+        break;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  X.tag++;
+  X.xno++;
+  Cand rc{0.0, 0.0, 0, 0};
+  if (lane < X.nw && !X.dead) rc = Cand{rec[0], rec[1], __double2loint(rec[2]), __double2hiint(rec[2])};
+  int wl;
+  const Cand win = wave_argbest<MODE>(rc, &wl);
+#pragma unroll
+  for (int k = 0; k < NP; k++) pout[k] = rl_d(rec[3 + k], wl);
+  return win;
+}
+
+template <int CPT, int RPT>
+__global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
+  extern __shared__ double hist[]; // [kmax][CPT + RPT][256]: scaled-row entries of this thread's columns, pivot-column entries of its rows
+  __shared__ Cand s_slots[2][4];
+  __shared__ double s_pay[2][4][5];
+  // the chain so far (every thread of the workgroup writes the same values) and, per wave, the operands of the carries
+  __shared__ int s_kind[KCH], s_p[KCH], s_q[KCH];
+  __shared__ double s_piv[KCH], s_ip[KCH], s_wv[4][2][KCH];
+  if (blockIdx.x & 7) return; // the workgroups that share an XCD with workgroup 0
+  const int w = (int)blockIdx.x >> 3, t = TIDX, lane = t & 63, wave = t >> 6;
+  Ctl *const c = A.c;
+  const int nw = A.nw, TT = nw * 256, gt = w * 256 + t;
+  const int m = A.m, n = A.n, kmax = A.kmax;
+  const size_t ld = (size_t)A.ld;
+  const double *const T = A.T;
+  const bool lead = (gt == 0);
+  unsigned long long *const dbg = c->dbg;
+#define CH_STAMP(K) do { if (dbg && lead) dbg[(size_t)g * 16 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  // ---- entry
+  const int done = c->done, fstate = c->fstate, budget = c->budget, perturbed = c->perturbed, aborted = c->cl_abort, epoch = c->pc_epoch;
+  int stall = c->stall;
+  double d[CPT], wgt[CPT], lbj[CPT], ubj[CPT], sqn[CPT];
+  int f[CPT], jj[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; u++) {
+    const int j = 1 + gt + u * TT;
+    const bool act = (j <= n);
+    const int jc = act ? j : n;
+    jj[u] = j;
+    d[u] = T[jc];
+    wgt[u] = A.pw[0][jc];
+    f[u] = act ? A.nflag[jc] : MVX_NS;
+    lbj[u] = A.nlb[jc];
+    ubj[u] = A.nub[jc];
+    sqn[u] = 0.0;
+  }
+  double z = T[0];
+  double be[RPT], lb[RPT], ub[RPT];
+  int ii[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {
+    const int i = 1 + gt + u * TT;
+    const int ic = (i <= m) ? i : m;
+    ii[u] = i;
+    be[u] = A.betab[ic];
+    lb[u] = A.blb[ic];
+    ub[u] = A.bub[ic];
+  }
+  if (done != D_RUN || fstate != F_RUN || aborted) return;
+  XCtx X;
+  X.rs = __builtin_amdgcn_make_buffer_rsrc(A.xg, 0, A.xg_bytes, 0x00027000);
+  X.w = w;
+  X.nw = nw;
+  X.tag = A.tagbase + 1;
+  X.xno = 0;
+  X.xabort = A.xabort;
+  X.dead = false;
+#define HS(S, U) hist[((size_t)(S) * (CPT + RPT) + (U)) * 256 + t]
+#define HC(S, U) hist[((size_t)(S) * (CPT + RPT) + CPT + (U)) * 256 + t]
+  int g = 0, used = 0;
+  // pricing of this thread's columns -> candidate with payload {d, w, lb, ub, entry in the newest scaled row}
+  Cand pc;
+  double pp[5], po[5];
+#define PRICE()                                                                                          \
+  do {                                                                                                   \
+    pc = Cand{0.0, 0.0, 0, 0};                                                                           \
+    pp[0] = d[0]; pp[1] = wgt[0]; pp[2] = lbj[0]; pp[3] = ubj[0]; pp[4] = sqn[0];                        \
+    _Pragma("unroll") for (int u = 0; u < CPT; u++) {                                                    \
+      Cand x{0.0, 0.0, 0, 0};                                                                            \
+      if (f[u] != MVX_NS && price_col(f[u], A.sgn * d[u], A.tol_dj, jj[u], wgt[u], x) && cand_better<0>(x, pc)) { \
+        pc = x;                                                                                          \
+        pc.aux = (x.aux > 0 ? 1 : 0) | (f[u] << 1);                                                      \
+        pp[0] = d[u]; pp[1] = wgt[u]; pp[2] = lbj[u]; pp[3] = ubj[u]; pp[4] = sqn[u];                    \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
+  PRICE();
+  Cand qc = xchg<0, 5>(X, pc, pp, po, s_slots, s_pay);
+  for (;;) {
+    if (X.dead) break;
+    const int q = qc.idx;
+    const bool none = (q == 0);
+    const int left = (budget < 0) ? 1 : budget - used;
+    if (none || left <= 0 || stall >= A.stall_limit) {
+      if (lead && g == 0) {
+        c->fstate = F_STOP;
+        c->phase = PH_PRIMAL2;
+        // the pivot limit with an entering column still on offer and nothing perturbed is what the generic step would
+        // report as it stands (select_step: price, then `budget == 0` -> D_ITLIM)
+        if (!none && left <= 0 && stall < A.stall_limit && !perturbed) {
+          c->done = D_ITLIM;
+          c->step = ST_NONE;
+        }
+      }
+      break;
+    }
+    if (g >= kmax) break;
+    CH_STAMP(0);
+    const int sdir = (qc.aux & 1) ? 1 : -1, fq = qc.aux >> 1;
+    const double dq = po[0], wq = po[1], lbq = po[2], ubq = po[3];
+    // ---- column phase: column q of this thread's rows, the entries of the earlier scaled rows in column q
+    double a[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) a[u] = T[(size_t)((ii[u] <= m) ? ii[u] : m) * ld + q];
+    {
+      double sqv = po[4]; // lane g-1: from the exchange; lanes below: from memory
+      if (lane < g - 1) sqv = ld_sc1(A.srow0 + (size_t)lane * A.sstride + q);
+      if (lane < g) s_wv[wave][0][lane] = sqv;
+    }
+    // the carry, eight steps to a block: the operands of a block are requested together (LDS), then the block's
+    // dependent multiply-adds run; which steps are pivots and which of them are the rare case -- the column that
+    // entered at step s enters again, c_i / piv of that step -- is known to the scalar unit beforehand
+    const int gu = __builtin_amdgcn_readfirstlane(g);
+    const bool ispc = (lane < gu) && (s_kind[lane < KCH ? lane : 0] == ST_PIVOT);
+    const unsigned pivm = (unsigned)__ballot(ispc);
+    const unsigned spc = (unsigned)__ballot(ispc && s_q[lane < KCH ? lane : 0] == q);
+    // (each SIMD runs one wave of this kernel, so every branch and every wait is paid in full: a block whose steps are
+    // all ordinary pivots -- nearly every block -- runs without a single branch; blocks of 8, 4, 2, 1 steps)
+    {
+      int s0 = 0;
+#define COL_BLOCK(N)                                                                                                     \
+  if (gu - s0 >= N) {                                                                                                    \
+    const unsigned bm = ((1u << N) - 1u) << s0;                                                                          \
+    double hc8[RPT][N], sq8[N];                                                                                          \
+    int lp8[N];                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < N; k++) {                                                                      \
+      sq8[k] = s_wv[wave][0][s0 + k];                                                                                    \
+      lp8[k] = s_p[s0 + k];                                                                                              \
+      _Pragma("unroll") for (int u = 0; u < RPT; u++) hc8[u][k] = HC(s0 + k, u);                                         \
+    }                                                                                                                    \
+    if ((pivm & bm) == bm && (spc & bm) == 0u) {                                                                         \
+      _Pragma("unroll") for (int k = 0; k < N; k++) {                                                                    \
+        _Pragma("unroll") for (int u = 0; u < RPT; u++) a[u] = (ii[u] == lp8[k]) ? -sq8[k] : fma(-hc8[u][k], sq8[k], a[u]); \
+      }                                                                                                                  \
+    } else {                                                                                                             \
+      _Pragma("unroll") for (int k = 0; k < N; k++) {                                                                    \
+        const int sx = s0 + k;                                                                                           \
+        if ((pivm >> sx) & 1u) {                                                                                         \
+          if ((spc >> sx) & 1u) {                                                                                        \
+            const double ips = s_ip[sx], pvs = s_piv[sx];                                                                \
+            _Pragma("unroll") for (int u = 0; u < RPT; u++) a[u] = (ii[u] == lp8[k]) ? ips : xdiv(hc8[u][k], pvs);       \
+          } else {                                                                                                       \
+            _Pragma("unroll") for (int u = 0; u < RPT; u++) a[u] = (ii[u] == lp8[k]) ? -sq8[k] : fma(-hc8[u][k], sq8[k], a[u]); \
+          }                                                                                                              \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    s0 += N;                                                                                                             \
+  }
+      while (gu - s0 >= 8) { COL_BLOCK(8) }
+      COL_BLOCK(4)
+      COL_BLOCK(2)
+      COL_BLOCK(1)
+#undef COL_BLOCK
+    }
+    CH_STAMP(1);
+    Cand rb{0.0, 0.0, 0, 0};
+    double rp[4] = {a[0], be[0], lb[0], ub[0]}, ro[4];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+      Cand x{0.0, 0.0, 0, 0};
+      if (ii[u] <= m) {
+        A.colq0[(size_t)g * A.cstride + ii[u]] = a[u];
+        if (ratio_row(a[u], sdir, be[u], lb[u], ub[u], 0, A.tol_piv, ii[u], x) && cand_better<1>(x, rb)) {
+          rb = x;
+          rp[0] = a[u]; rp[1] = be[u]; rp[2] = lb[u]; rp[3] = ub[u];
+        }
+      }
+      HC(g, u) = a[u];
+    }
+    CH_STAMP(2);
+    const Cand pw = xchg<1, 4>(X, rb, rp, ro, s_slots, s_pay);
+    if (X.dead) break;
+    CH_STAMP(3);
+    const int p = pw.idx, p_up = pw.aux;
+    const double tstep = pw.k1, piv = ro[0], bp = ro[1], plb = ro[2], pub = ro[3];
+    bool flip = false;
+    double tf = 0.0;
+    if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
+      tf = ubq - lbq;
+      if (p == 0 || tf <= tstep) flip = true;
+    }
+    if (!flip && p == 0) { // unbounded ray: the generic path reports it
+      if (lead && g == 0) {
+        c->fstate = F_STOP;
+        c->phase = PH_PRIMAL2;
+      }
+      break;
+    }
+    int kind, lf, stall_new;
+    double delta = 0.0, bound = 0.0, s0 = 0.0, xq = 0.0, ip = 1.0;
+    if (flip) {
+      kind = ST_FLIP;
+      lf = (sdir > 0) ? MVX_NU : MVX_NL;
+      delta = (sdir > 0) ? tf : -tf;
+      stall_new = 0;
+#pragma unroll
+      for (int u = 0; u < RPT; u++) be[u] = fma(a[u], delta, be[u]);
+      z = fma(dq, delta, z); // the objective value moves with the flipped variable
+#pragma unroll
+      for (int u = 0; u < CPT; u++) {
+        if (jj[u] == q) f[u] = lf;
+        sqn[u] = 0.0;
+      }
+    } else {
+      kind = ST_PIVOT;
+      bound = p_up ? pub : plb;
+      lf = dev_leave_flag(plb, pub, p_up);
+      s0 = xdiv(bp - bound, piv);
+      xq = dev_nb_value(fq, lbq, ubq);
+      ip = xdiv(1.0, piv);
+      stall_new = (tstep <= DEGEN_TOL) ? stall + 1 : 0;
+#pragma unroll
+      for (int u = 0; u < RPT; u++) {
+        if (ii[u] == p) {
+          be[u] = xq - s0;
+          lb[u] = lbq; // the entering variable comes to sit in row p
+          ub[u] = ubq;
+        } else
+          be[u] = fma(-a[u], s0, be[u]);
+      }
+      // ---- row phase: row p of this thread's columns, the entries of the earlier pivot columns in row p
+      double val[CPT];
+#pragma unroll
+      for (int u = 0; u < CPT; u++) val[u] = T[(size_t)p * ld + ((jj[u] <= n) ? jj[u] : n)];
+      CH_STAMP(4);
+      if (lane < g) {
+        const double rcp = ld_sc1(A.colq0 + (size_t)lane * A.cstride + p);
+        s_wv[wave][0][lane] = rcp;
+        s_wv[wave][1][lane] = xdiv(rcp, s_piv[lane]);
+      }
+      // the rare case here: the row that left at step s leaves again, -s_j of that step
+      const unsigned spr = (unsigned)__ballot(ispc && s_p[lane < KCH ? lane : 0] == p);
+      {
+        int s0 = 0;
+#define ROW_BLOCK(N)                                                                                                     \
+  if (gu - s0 >= N) {                                                                                                    \
+    const unsigned bm = ((1u << N) - 1u) << s0;                                                                          \
+    double hs8[CPT][N], cp8[N], cd8[N];                                                                                  \
+    int lq8[N];                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < N; k++) {                                                                      \
+      cp8[k] = s_wv[wave][0][s0 + k];                                                                                    \
+      cd8[k] = s_wv[wave][1][s0 + k];                                                                                    \
+      lq8[k] = s_q[s0 + k];                                                                                              \
+      _Pragma("unroll") for (int u = 0; u < CPT; u++) hs8[u][k] = HS(s0 + k, u);                                         \
+    }                                                                                                                    \
+    if ((pivm & bm) == bm && (spr & bm) == 0u) {                                                                         \
+      _Pragma("unroll") for (int k = 0; k < N; k++) {                                                                    \
+        _Pragma("unroll") for (int u = 0; u < CPT; u++) val[u] = (jj[u] == lq8[k]) ? cd8[k] : fma(-cp8[k], hs8[u][k], val[u]); \
+      }                                                                                                                  \
+    } else {                                                                                                             \
+      _Pragma("unroll") for (int k = 0; k < N; k++) {                                                                    \
+        const int sx = s0 + k;                                                                                           \
+        if ((pivm >> sx) & 1u) {                                                                                         \
+          if ((spr >> sx) & 1u) {                                                                                        \
+            const double ips = s_ip[sx];                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < CPT; u++) val[u] = (jj[u] == lq8[k]) ? ips : -hs8[u][k];               \
+          } else {                                                                                                       \
+            _Pragma("unroll") for (int u = 0; u < CPT; u++) val[u] = (jj[u] == lq8[k]) ? cd8[k] : fma(-cp8[k], hs8[u][k], val[u]); \
+          }                                                                                                              \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    s0 += N;                                                                                                             \
+  }
+        while (gu - s0 >= 8) { ROW_BLOCK(8) }
+        ROW_BLOCK(4)
+        ROW_BLOCK(2)
+        ROW_BLOCK(1)
+#undef ROW_BLOCK
+      }
+      CH_STAMP(5);
+#pragma unroll
+      for (int u = 0; u < CPT; u++) {
+        const int j = jj[u];
+        const double sj = xdiv(val[u], piv);
+        if (j == q) {
+          d[u] = xdiv(dq, piv);
+          const double cc = xdiv(wq, piv * piv);
+          wgt[u] = cc > 1.0 ? cc : 1.0;
+          lbj[u] = plb; // the leaving variable comes to sit in column q
+          ubj[u] = pub;
+          f[u] = lf;
+        } else {
+          d[u] = fma(-dq, sj, d[u]);
+          const double cc = sj * sj * wq;
+          wgt[u] = cc > wgt[u] ? cc : wgt[u];
+        }
+        if (j <= n) A.srow0[(size_t)g * A.sstride + j] = sj;
+        HS(g, u) = sj;
+        sqn[u] = sj;
+      }
+      z = fma(-dq, s0, z);
+      if (lead) A.srow0[(size_t)g * A.sstride] = s0;
+    }
+    // ---- the step is chosen: every wave notes it in lane g, workgroup 0 writes it down for the bulk pass
+    s_kind[g] = kind; // read from the next step on, behind the barrier of the exchange that follows
+    s_p[g] = flip ? 0 : p;
+    s_q[g] = q;
+    s_piv[g] = flip ? 1.0 : piv;
+    s_ip[g] = ip;
+    used += flip ? 0 : 1;
+    if (lead) {
+      c->ch_kind[g] = kind;
+      c->ch_p[g] = flip ? 0 : p;
+      c->ch_q[g] = q;
+      c->ch_lf[g] = lf;
+      c->ch_piv[g] = flip ? 1.0 : piv;
+      c->ch_xq[g] = xq;
+      c->ch_s0[g] = s0;
+      c->ch_delta[g] = delta;
+      c->ch_elb[g] = lbq;
+      c->ch_eub[g] = ubq;
+      c->ch_llb[g] = plb;
+      c->ch_lub[g] = pub;
+      c->ch_bound[g] = bound;
+      c->ch_pup[g] = p_up;
+      c->ch_stall[g] = stall_new;
+      c->ch_cnt[g] = used;
+      c->ch_ok[g] = epoch;
+    }
+    CH_STAMP(6);
+    PRICE();
+    CH_STAMP(7);
+    stall = stall_new;
+    g++;
+    qc = xchg<0, 5>(X, pc, pp, po, s_slots, s_pay);
+    if (dbg && lead) dbg[(size_t)(g - 1) * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+  }
+#undef PRICE
+#undef CH_STAMP
+#undef HS
+#undef HC
+  if (X.dead) { // a peer never showed up: nothing has been changed, the host falls back on k_pc / k_pr
+    if (lead) {
+      c->pc_n = 0;
+      c->cl_abort = 1;
+    }
+    return;
+  }
+  // ---- the chain is complete: the column side as the last step leaves it, where the bulk pass looks for it
+  if (g > 0) {
+    const int xf = g & 1;
+#pragma unroll
+    for (int u = 0; u < CPT; u++) {
+      if (jj[u] <= n) {
+        A.drowk[xf][jj[u]] = d[u];
+        A.pwk[xf][jj[u]] = wgt[u];
+      }
+    }
+    if (lead) {
+      A.drowk[xf][0] = z;
+      A.pwk[xf][0] = 1.0;
+    }
+  }
+  if (lead) {
+    c->pc_n = g;
+    if (g > 0) c->phase = PH_PRIMAL2;
+  }
+}
+
 // The chain's bookkeeping (one workgroup, every thread calls): the basis swaps of the chain in order -- a swap exchanges
 // (variable, bounds) between row p_t and column q_t.  The bounds need no exchange: the selection recorded what enters
 // row p_t (ch_elb / ch_eub) and what comes to sit in column q_t (ch_llb / ch_lub), so the last step that touches a row
@@ -3112,6 +3629,41 @@ void launch_pstep(const ChainArgs &a, int g, hipStream_t s) {
   hipLaunchKernelGGL(k_pr, dim3(a.ncb), dim3(256), 0, s, a, g);
 }
 void launch_pc(const ChainArgs &a, int g, hipStream_t s) { hipLaunchKernelGGL(k_pc, dim3(a.nrb), dim3(256), 0, s, a, g); }
+// k_chain: nw workgroups of 256 threads cover the rows and the columns CPT / RPT to a thread; LDS = the chain's history
+int chain_cluster_nw(int m, int n) {
+  const int span = m > n ? m : n;
+  int nw = (span + 255) / 256;
+  if (nw > 32) nw = 32;
+  return nw < 1 ? 1 : nw;
+}
+// longest chain k_chain can keep in LDS for this geometry (0: the geometry is not covered)
+int chain_cluster_kmax(int m, int n) {
+  const int nw = chain_cluster_nw(m, n), tt = nw * 256;
+  const int cpt = (n + tt - 1) / tt, rpt = (m + tt - 1) / tt;
+  if (cpt > 2 || rpt > 2) return 0;
+  const int per_step = (cpt > 1 || rpt > 1 ? 4 : 2) * 256 * 8;
+  const int k = (140 * 1024) / per_step;
+  return k > KCH ? KCH : k;
+}
+int launch_chain(const ChainArgs &a, hipStream_t s) {
+  const int tt = a.nw * 256;
+  const int cpt = (a.n + tt - 1) / tt, rpt = (a.m + tt - 1) / tt;
+  const bool wide = (cpt > 1 || rpt > 1);
+  const size_t lds = (size_t)(a.kmax > 0 ? a.kmax : 1) * (wide ? 4 : 2) * 256 * 8;
+  static size_t attr1 = 0, attr2 = 0;
+  size_t &attr = wide ? attr2 : attr1;
+  const void *fn = wide ? reinterpret_cast<const void *>(k_chain<2, 2>) : reinterpret_cast<const void *>(k_chain<1, 1>);
+  if (lds > attr) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    attr = lds;
+  }
+  if (wide) hipLaunchKernelGGL((k_chain<2, 2>), dim3(8 * a.nw), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((k_chain<1, 1>), dim3(8 * a.nw), dim3(256), lds, s, a);
+  return 0;
+}
 void launch_fpatch(const ChainArgs &a, int steps, hipStream_t s) {
   const int span = a.mcap1 > a.n + 1 ? a.mcap1 : a.n + 1;
   hipLaunchKernelGGL(k_fpatch, dim3((span + 255) / 256, 2 * steps + 1), dim3(256), 0, s, a, steps);
