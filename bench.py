@@ -2,9 +2,10 @@
 """bench.py -- simplex pivots/s on a dense fp64 tableau, with the HBM roofline of the rank-1
 update kernel and a same-host CPU baseline (BASELINE.json metric).
 
-One "step" = one simplex pivot (k_fa: selection + pivot row; k_fb: the streamed Gauss-Jordan rank-1
-update) on the synthetic dense LP of BASELINE.md config 4: m=4096, n=8192, fp64, splitmix64 seed
-12345 (+rank).  The tableau is resident in HBM before the timed region starts; a run longer than the
+One "step" = one simplex pivot on the synthetic dense LP of BASELINE.md config 4: m=4096, n=8192, fp64, splitmix64 seed
+12345 (+rank).  The pivots are chained: k_chain chooses up to 32 of them from O(m+n) slices of the tableau as it stands,
+then ONE pass over the tableau (k_fbc3, the streamed Gauss-Jordan update: HBM-bound) applies them all, k_fpatch writes
+the chain's pivot rows / columns.  The tableau is resident in HBM before the timed region starts; a run longer than the
 LP's ~3.4k pivots to optimality carries on with a device-to-device clone of the initial tableau.
 
   python bench.py --gpus N --steps K --warmup W
@@ -36,20 +37,21 @@ def bytes_per_pivot(m, n):
 
 
 def pmc_traffic(m, n):
-    """HBM bytes per k_fb launch from the committed rocprofv3 PMC passes (profiles/*traffic*.json,
-    written by scripts/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when not measured."""
+    """HBM bytes per bulk launch from the committed rocprofv3 PMC passes (profiles/*traffic*.json, written by
+    scripts/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for wide coalesced reads on gfx950).  A constant shipped with the repo, NOT measured in this run:
+    returns (bytes, source file) of the newest matching record, (None, None) when there is none."""
     import glob
 
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("m") == m and d.get("n") == n and d.get("bytes_per_launch"):
-            best = d["bytes_per_launch"]
-    return best
+            best, src = d["bytes_per_launch"], os.path.relpath(f, ROOT)
+    return best, src
 
 
 def glpk_probe(A, b, c, budget_pivots=400):
@@ -231,7 +233,7 @@ def secondary(api, with_cpu=True):
     return out
 
 
-def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=lambda res: None):
+def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=lambda res: None, note=lambda phase: None):
     """secondary.bnb_ilp_512x1024_dist (every rank calls this): the serial-equivalent node farm over the process
     group -- node LPs sharded over the ranks (bs.cpp:96-327), MAX all-reduces for the incumbent and the child bounds,
     RCCL send/recv for the children that change ranks.  Two instances, as in secondary(): the wide 512x1024 tree
@@ -243,6 +245,7 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=la
 
     eng = dist_bnb.HipNodeEngine(dev_index, comm_device="cpu" if rehearsal else None)
     A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3, 0.4)
+    note("warm-up")
     dist_bnb.branch_and_bound(eng, synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=4 * world * 16, per_rank=16)  # warm-up
 
     def timed(inst, quirks, max_nodes, deal):
@@ -262,7 +265,9 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=la
                    "migrated_images": st["migrated"], "migrated_share": st["migrated"] / max(1, st["children"]),
                    "migrated_bytes_per_node": st["migrated_bytes"] / max(1, r["count"]), "rounds": st["rounds"]}
 
+    note("wide tree, children on their parent's rank")
     r_own, own = timed((A, b, c, U), 0, nodes, "owner")
+    note("wide tree, children dealt round-robin")
     r_rr, rr = timed((A, b, c, U), 0, nodes, "roundrobin")
     res = dict(own)
     res["instance"] = "wide (cap 0.4, U 3), first %d nodes" % nodes
@@ -273,6 +278,7 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=la
     res["roundrobin_dealing"] = {k: rr[k] for k in ("nodes_per_s", "migrated_images", "migrated_share", "migrated_bytes_per_node")}
     fx, inst5 = config5_instance()
     if fx.get("full"):
+        note("config-5 tree")
         r5, c5 = timed(inst5, int(fx.get("reference_quirks", 0)), 0, "owner")
         c5["instance"] = "calibrated config 5 (cap %g, U %g): the whole tree" % (fx["cap"], fx["U"])
         c5["same_tree_as_oracle_fixture"] = treedigest.digest(r5) == fx["full"]["sha256"]
@@ -289,6 +295,7 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=la
     res["native_coordinator"] = {"error": "did not finish"}
     publish(dict(res))
     if os.environ.get("MVX_BENCH_NO_NATIVE_DIST") != "1":
+        note("native coordinator (mvx_branchAndBound_dist)")
         try:
             from mvolps_amd import dist_native
 
@@ -449,32 +456,47 @@ def main():
     # two event records per pivot cost ~6 us/pivot (scripts/evcost.py), which would distort `value`.
     roof = None
     if rank == 0:
-        api.profile_reset()
-        api.profile_enable(1)
-        pivots = run_pivots(args.profile_steps)
-        api.profile_enable(0)
-        # events were recorded around every queued launch; only launches that pivoted moved data,
-        # the queued-ahead no-op launches after the limit are a few microseconds each
-        k_ms = api.profile_update_ms()
-        k_n = api.profile_update_launches()
+        def timed_passes(pivots_wanted):
+            api.profile_reset()
+            api.profile_enable(1)
+            done = run_pivots(pivots_wanted)
+            api.profile_enable(0)
+            # events were recorded around every queued bulk launch (k_fbc3 alone); only launches that stepped count
+            return done, api.profile_update_ms(), api.profile_update_launches()
+
+        pivots, k_ms, k_n = timed_passes(args.profile_steps)
         if pivots > 0 and k_ms > 0 and k_n > 0:
             # one bulk launch reads and writes the tableau once, whether it applies one pivot or a chain of them
             avg_ms = k_ms / k_n
             achieved = bytes_per_pivot(m, n) / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(m, n)
             roof = {
                 "bound": "hbm",
-                "kernel": "k_fbc / k_fb (streamed Gauss-Jordan update, one pass over the tableau per launch)",
+                "kernel": "k_fbc3 (streamed Gauss-Jordan update: one pass over the tableau per launch, every step of the chain applied in registers)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(m, n),
+                "traffic": traffic,
+                "traffic_source": ("%s (committed rocprofv3 PMC pass, not measured in this run)" % traffic_src) if traffic_src else None,
                 "avg_launch_us": avg_ms * 1e3,
                 "launches_timed": k_n,
                 "pivots_timed": pivots,
                 "pivots_per_launch": pivots / k_n,
                 "bytes_per_launch": bytes_per_pivot(m, n),
             }
+            # the same kernel with ONE pivot per pass (the rank-1 update the north star prices: MVX_CHAIN=1), timed in
+            # this run over >= 50 launches
+            try:
+                api.set_chain(1)
+                run_pivots(5)
+                p1, ms1, n1 = timed_passes(60)
+                if p1 > 0 and ms1 > 0 and n1 > 0:
+                    a1 = bytes_per_pivot(m, n) / (ms1 / n1 * 1e-3) / 1e9
+                    roof["rank1"] = {"achieved": a1, "frac": a1 / HBM_PEAK_GBS, "avg_launch_us": ms1 / n1 * 1e3, "launches_timed": n1,
+                                     "what": "k_fbc3 with one pivot per pass (mvx_set_chain(1)): the plain rank-1 update"}
+            finally:
+                api.set_chain(0)
 
     dist_leg = None
     leg_hung = False
@@ -491,7 +513,7 @@ def main():
             try:
                 torch.cuda.set_device(dev_index)
                 api.bind_thread()
-                box["res"] = dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, args.bnb_nodes, lambda part: box.__setitem__("part", part))
+                box["res"] = dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, args.bnb_nodes, lambda part: box.__setitem__("part", part), lambda ph: box.__setitem__("phase", ph))
             except Exception as e:  # the failure modes that raise are deterministic (fixture, engine): every rank raises
                 box["res"] = {"error": repr(e)}
 
@@ -552,7 +574,10 @@ def main():
         print(json.dumps(out), flush=True)
     sys.stdout.flush()
     if leg_hung:
-        os._exit(0)  # a collective is stuck on the helper thread: leave without joining it
+        sys.stderr.write("bench.py rank %d: the distributed B&B leg did not finish before its deadline (stuck in: %s); the headline line was printed first\n"
+                         % (rank, (box.get("phase") or "unknown phase")))
+        sys.stderr.flush()
+        os._exit(3)  # a collective is stuck on the helper thread: leave without joining it, and say so in the exit code
     if dist is not None:
         # leave together, but never wait for a peer that gave up on the side leg
         import threading
@@ -568,7 +593,9 @@ def main():
         th.start()
         th.join(60.0)
         if th.is_alive():
-            os._exit(0)
+            sys.stderr.write("bench.py rank %d: the farewell barrier timed out\n" % rank)
+            sys.stderr.flush()
+            os._exit(4)
 
 
 if __name__ == "__main__":

@@ -1335,7 +1335,11 @@ __global__ __launch_bounds__(256) void k_export(Ctl *c, unsigned char *stage, in
   c += blockIdx.z;
   stage += (size_t)blockIdx.z * slot_stride;
   const int t = (int)blockIdx.x * 256 + TIDX;
-  if (t == 0) *reinterpret_cast<Ctl *>(stage) = *c;
+  if (blockIdx.x == 0) { // the control block, a word per thread (one thread copying its 6 KB alone took 12 us)
+    const unsigned *src = reinterpret_cast<const unsigned *>(c);
+    unsigned *dst = reinterpret_cast<unsigned *>(stage);
+    for (int w = TIDX; w < (int)(sizeof(Ctl) / 4); w += 256) dst[w] = src[w];
+  }
   if (c->T == nullptr) return; // idle slot of a batched launch
   if (!force && c->done == D_RUN) return;
   pack_mirrors(c, stage, t, (int)gridDim.x * 256);
@@ -2672,6 +2676,7 @@ __device__ void chain_commit(const ChainArgs &A, Ctl *c, int nch) {
 typedef const double __attribute__((address_space(4))) *kconst_f64;
 template <int TR, int NT>
 __global__ __launch_bounds__(256) void k_fbc3(const ChainArgs A) {
+  __shared__ double s_cq[KCH][TR]; // the tile's rows of every step's pivot column (zeros for a bound flip)
   Ctl *const c = A.c;
   if (c->done != D_RUN || c->fstate != F_RUN) return;
   const int nch = c->pc_n;
@@ -2681,44 +2686,58 @@ __global__ __launch_bounds__(256) void k_fbc3(const ChainArgs A) {
   const int j0 = 2 * ((int)blockIdx.x * 256 + TIDX);
   const int i0 = 1 + (int)blockIdx.y * TR;
   const int xf = nch & 1; // the set the chain's last step wrote
-  if (j0 <= n) {
-  double *base = A.T + (size_t)i0 * ld + j0;
+  const bool act = (j0 <= n);
+  const int jc = act ? j0 : 0;
+  double *base = A.T + (size_t)i0 * ld + jc;
   double2 v[TR];
 #pragma unroll
   for (int r = 0; r < TR; r++) v[r] = ld2<NT>(reinterpret_cast<const double2 *>(base + (size_t)r * ld));
   unsigned flips = 0; // which steps are bound flips: known before the loop, so no step waits for its own description
   for (int l = 0; l < nch; l++) flips |= (c->ch_kind[l] == ST_FLIP) ? (1u << l) : 0u;
-  const double *sp = A.srow0 + j0;
-  const double *zp = A.zeros + j0;
-  double2 s = *reinterpret_cast<const double2 *>((flips & 1u) ? zp : sp);
-  for (int l = 0; l < nch; l++) {
-    const bool flip = (flips >> l) & 1u;
-    const kconst_f64 cq = (kconst_f64)(flip ? A.zeros : A.colq0 + (size_t)l * A.cstride + i0);
-    // the next step's pair of the scaled pivot row is requested before this step's multiply-adds
-    const int ln = (l + 1 < nch) ? l + 1 : l;
-    const double2 sn = *reinterpret_cast<const double2 *>(((flips >> ln) & 1u) ? zp : sp + (size_t)ln * A.sstride);
+  for (int e = TIDX; e < nch * TR; e += 256) {
+    const int l = e / TR, r = e % TR;
+    s_cq[l][r] = ((flips >> l) & 1u) ? 0.0 : A.colq0[(size_t)l * A.cstride + i0 + r];
+  }
+  __syncthreads();
+  const double *sp = A.srow0 + jc;
+  const double *zp = A.zeros + jc;
+  // four steps to a group: the group's pairs of the scaled pivot rows are requested together, so that one memory round
+  // trip is paid per group and not per step
+  for (int l0 = 0; l0 < nch; l0 += 4) {
+    double2 s4[4];
 #pragma unroll
-    for (int r = 0; r < TR; r++) {
-      // in place (an instruction with a tied operand)
-      const double ci = cq[r];
-      asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(v[r].x) : "s"(ci), "v"(s.x));
-      asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(v[r].y) : "s"(ci), "v"(s.y));
+    for (int k = 0; k < 4; k++) {
+      const int lk = (l0 + k < nch) ? l0 + k : nch - 1;
+      s4[k] = *reinterpret_cast<const double2 *>(((flips >> lk) & 1u) ? zp : sp + (size_t)lk * A.sstride);
     }
-    s = sn;
-  }
-  if (j0 == 0) {
 #pragma unroll
-    for (int r = 0; r < TR; r++) base[(size_t)r * ld + 1] = v[r].y;
-  } else {
+    for (int k = 0; k < 4; k++) {
+      if (l0 + k < nch) {
 #pragma unroll
-    for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
+        for (int r = 0; r < TR; r++) {
+          // v = fma(-c_i, s_j, v) in place (an instruction with a tied operand: left to itself the compiler gives each
+          // step's results new registers and copies the whole tile back)
+          const double ci = s_cq[l0 + k][r];
+          asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(v[r].x) : "v"(ci), "v"(s4[k].x));
+          asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(v[r].y) : "v"(ci), "v"(s4[k].y));
+        }
+      }
+    }
   }
-  if (blockIdx.y == 0) { // the objective row and the weights live outside the row blocks: back to where the other paths read them
-    *reinterpret_cast<double2 *>(A.T + j0) = *reinterpret_cast<const double2 *>(A.drowk[xf] + j0);
-    const double2 w = *reinterpret_cast<const double2 *>(A.pwk[xf] + j0);
-    *reinterpret_cast<double2 *>(A.pw[0] + j0) = w;
-    *reinterpret_cast<double2 *>(A.pw[1] + j0) = w;
-  }
+  if (act) {
+    if (j0 == 0) {
+#pragma unroll
+      for (int r = 0; r < TR; r++) base[(size_t)r * ld + 1] = v[r].y;
+    } else {
+#pragma unroll
+      for (int r = 0; r < TR; r++) st2<NT>(reinterpret_cast<double2 *>(base + (size_t)r * ld), v[r]);
+    }
+    if (blockIdx.y == 0) { // the objective row and the weights live outside the row blocks: back to where the other paths read them
+      *reinterpret_cast<double2 *>(A.T + j0) = *reinterpret_cast<const double2 *>(A.drowk[xf] + j0);
+      const double2 w = *reinterpret_cast<const double2 *>(A.pwk[xf] + j0);
+      *reinterpret_cast<double2 *>(A.pw[0] + j0) = w;
+      *reinterpret_cast<double2 *>(A.pw[1] + j0) = w;
+    }
   }
   // the first workgroup to be dispatched also commits the chain's bookkeeping, beside the rest of the pass
   if (blockIdx.x == 0 && blockIdx.y == 0) chain_commit(A, c, nch);
@@ -3668,11 +3687,14 @@ void launch_fpatch(const ChainArgs &a, int steps, hipStream_t s) {
   const int span = a.mcap1 > a.n + 1 ? a.mcap1 : a.n + 1;
   hipLaunchKernelGGL(k_fpatch, dim3((span + 255) / 256, 2 * steps + 1), dim3(256), 0, s, a, steps);
 }
-void launch_fbc3(const ChainArgs &a, hipStream_t s) {
+void launch_fbc3(const ChainArgs &a, int steps, hipStream_t s) {
   const int m = a.m, n = a.n;
   const int pairs = (n + 2) / 2;
   int tr = pick_tr(m, n);
   if (tr > 16) tr = 16;
+  // long chains: shallower tiles, more waves to a SIMD to cover the per-step operand fetches (scripts/bulktime.py:
+  // 4096x8192, 32 steps: 117.7 us with 16-row tiles, 104.8 with 8; 10 steps: 82.3 / 81.6; one step: 76.1 / 79.6)
+  if (!g_tr && tr == 16 && steps >= 12) tr = 8;
   const int nt = pick_nt(m, n);
   dim3 grid((pairs + 255) / 256, (m + tr - 1) / tr);
 #define FBC2_CASE(TR_, NT_) \
