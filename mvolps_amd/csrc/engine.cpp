@@ -1000,7 +1000,7 @@ static void job_begin(Context &c, SolveJob &J) {
     a.stall_limit = h->stall_limit;
     a.zeros = sc.d_zeros;
     a.xg = sc.d_xg; a.xg_bytes = (int)XG_BYTES; a.xabort = sc.d_xabort;
-    a.nw = chain_cluster_nw(P->m, P->n); a.kmax = 0; a.tagbase = 0;
+    a.nw = chain_cluster_nw(P->m, P->n); a.kmax = 0; a.tagbase = 0; a.boot = 0;
   }
   J.cluster = cluster_wanted() && chain_cluster_kmax(P->m, P->n) > 0;
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
@@ -1092,11 +1092,14 @@ static void job_enqueue(Context &c, SolveJob &J) {
           // chained path: k_pboot once, then per chain of up to `kc` steps two small launches per step (k_pc / k_pr)
           // and one bulk launch (k_fbc3), so `depth` pivots take depth / kc passes over the tableau when every chain
           // fills (a chain that ends early leaves pivots for the next batch)
-          launch_pboot(J.cargs, sc.stream);
           const bool cl = J.cluster && !g_cluster_broken.load();
+          if (!cl) launch_pboot(J.cargs, sc.stream); // k_chain does the start-of-batch checks itself (first launch: boot)
+          bool first = true;
           const int kc = cl ? std::max(1, std::min(J.chain0, chain_cluster_kmax(m, n))) : std::max(1, J.chain);
           auto chain_launch = [&](int steps) { // k_chain: the whole selection of a chain of up to `steps` steps
             J.cargs.kmax = steps;
+            J.cargs.boot = first ? 1 : 0;
+            first = false;
             J.cargs.tagbase = sc.xtag;
             sc.xtag += 128;
             if (launch_chain(J.cargs, sc.stream) != 0) g_cluster_broken.store(true);
@@ -1114,10 +1117,8 @@ static void job_enqueue(Context &c, SolveJob &J) {
             left -= steps;
           }
           // a run that may end on the pivot limit: one more selection, which finds the limit and reports it
-          if (J.parm.it_lim >= 0 && depth >= remaining) {
-            if (cl) chain_launch(0);
-            else launch_pc(J.cargs, 0, sc.stream);
-          }
+          // (k_chain notes it itself when the limit falls on the end of its last chain: pc_itlim)
+          if (J.parm.it_lim >= 0 && depth >= remaining && !cl) launch_pc(J.cargs, 0, sc.stream);
         }
         launch_select(sc.d_ctl, sc.stream);
         if (J.profiled) HIPCHECK(hipEventRecord(c.ev_pool[e_generic], sc.stream));

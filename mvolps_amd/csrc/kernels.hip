@@ -657,6 +657,15 @@ __device__ int dual_chain(const KC &k, Ctl *c, Cand *lds, int kmax) {
 __device__ void select_step(Ctl *c, Cand *lds) {
   const KC k = load_kc(c); // every pointer / constant the step needs, fetched in one burst
   if (c->done != D_RUN) return;
+  if (c->pc_itlim) { // k_chain saw the pivot limit fall on the end of its chain, with an entering column still on offer
+    __syncthreads();
+    if (TIDX == 0) {
+      c->pc_itlim = 0;
+      c->fstate = F_STOP;
+    }
+    dev_finish(c, D_ITLIM, PH_PRIMAL2, c->rounds);
+    return;
+  }
   if (TIDX == 0) c->nch = 1; // whatever step this call prepares is a single one unless a dual chain says otherwise below
   const int ne = c->n_edits;
   if (ne) { // first step of a solve: the bound edits made since the last one (one lane each)
@@ -2107,6 +2116,7 @@ struct XCtx {
   int xno;      // exchanges so far
   int *xabort;
   bool dead;
+  bool flag; // in: this thread's contribution to the OR the next exchange carries; out: the OR over the whole cluster
 };
 
 __device__ __forceinline__ double ld_sc1(const double *p) {
@@ -2164,7 +2174,8 @@ __device__ __forceinline__ Cand xchg(XCtx &X, Cand mine, const double (&pin)[NP]
   const int lane = TIDX & 63, wave = TIDX >> 6, b = X.xno & 1;
   // workgroup level
   int ol;
-  const Cand wb = wave_argbest<MODE>(mine, &ol);
+  Cand wb = wave_argbest<MODE>(mine, &ol);
+  wb.aux = (wb.aux & 0xffff) | (__ballot(X.flag) ? 0x10000 : 0); // the flag rides in the record's aux word
   if (lane == 0) s_slots[b][wave] = wb;
 #pragma unroll
   for (int k = 0; k < NP; k++) {
@@ -2173,15 +2184,17 @@ __device__ __forceinline__ Cand xchg(XCtx &X, Cand mine, const double (&pin)[NP]
   }
   __syncthreads();
   Cand bb = s_slots[b][0];
-  int bw = 0;
+  int bw = 0, fl = bb.aux & 0x10000;
 #pragma unroll
   for (int k = 1; k < 4; k++) {
     const Cand y = s_slots[b][k];
+    fl |= y.aux & 0x10000;
     if (cand_better<MODE>(y, bb)) {
       bb = y;
       bw = k;
     }
   }
+  bb.aux = (bb.aux & 0xffff) | fl;
   const unsigned tag = X.tag;
   const unsigned reg = (unsigned)(X.xno & 3) * (unsigned)(XNF * XNW * 16);
   if (TIDX < 3 + NP) {
@@ -2221,7 +2234,9 @@ __device__ __forceinline__ Cand xchg(XCtx &X, Cand mine, const double (&pin)[NP]
   Cand rc{0.0, 0.0, 0, 0};
   if (lane < X.nw && !X.dead) rc = Cand{rec[0], rec[1], __double2loint(rec[2]), __double2hiint(rec[2])};
   int wl;
-  const Cand win = wave_argbest<MODE>(rc, &wl);
+  Cand win = wave_argbest<MODE>(rc, &wl);
+  X.flag = __ballot((rc.aux & 0x10000) != 0) != 0ull;
+  win.aux = (int)(short)(win.aux & 0xffff);
 #pragma unroll
   for (int k = 0; k < NP; k++) pout[k] = rl_d(rec[3 + k], wl);
   return win;
@@ -2246,8 +2261,18 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
   unsigned long long *const dbg = c->dbg;
 #define CH_STAMP(K) do { if (dbg && lead) dbg[(size_t)g * 16 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   // ---- entry
-  const int done = c->done, fstate = c->fstate, budget = c->budget, perturbed = c->perturbed, aborted = c->cl_abort, epoch = c->pc_epoch;
+  const int done = c->done, fstate0 = c->fstate, budget = c->budget, perturbed = c->perturbed, aborted = c->cl_abort, epoch = c->pc_epoch;
+  const int phase0 = c->phase, n_edits = c->n_edits, cur0 = c->curA & 1;
   int stall = c->stall;
+  // The first chain launch of a batch decides what k_pboot decides for k_pc / k_pr: a call that has just begun (phase
+  // PH_START, no bound edits waiting) is taken from its first pivot if no basic variable lies outside its bounds by more
+  // than the tolerance -- every thread looks at its own rows, the verdict rides on the first exchange -- and then the
+  // devex weights restart from one, as the generic step's `fresh_primal` does; a run already in primal phase 2 carries
+  // on; anything else (dual simplex, phase 1, Bland's rule in force) turns the pipeline off.
+  const bool boot = (A.boot != 0);
+  const bool fresh = boot && (phase0 == PH_START);
+  const int fstate = boot ? F_RUN : fstate0;
+  const bool boot_off = boot && (stall >= A.stall_limit || !(phase0 == PH_PRIMAL2 || (fresh && n_edits == 0)));
   double d[CPT], wgt[CPT], lbj[CPT], ubj[CPT], sqn[CPT];
   int f[CPT], jj[CPT];
 #pragma unroll
@@ -2257,7 +2282,7 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
     const int jc = act ? j : n;
     jj[u] = j;
     d[u] = T[jc];
-    wgt[u] = A.pw[0][jc];
+    wgt[u] = fresh ? 1.0 : A.pw[boot ? cur0 : 0][jc];
     f[u] = act ? A.nflag[jc] : MVX_NS;
     lbj[u] = A.nlb[jc];
     ubj[u] = A.nub[jc];
@@ -2271,11 +2296,15 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
     const int i = 1 + gt + u * TT;
     const int ic = (i <= m) ? i : m;
     ii[u] = i;
-    be[u] = A.betab[ic];
+    be[u] = boot ? T[(size_t)ic * ld] : A.betab[ic];
     lb[u] = A.blb[ic];
     ub[u] = A.bub[ic];
   }
   if (done != D_RUN || fstate != F_RUN || aborted) return;
+  if (boot_off) {
+    if (lead) c->fstate = F_OFF;
+    return;
+  }
   XCtx X;
   X.rs = __builtin_amdgcn_make_buffer_rsrc(A.xg, 0, A.xg_bytes, 0x00027000);
   X.w = w;
@@ -2284,6 +2313,17 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
   X.xno = 0;
   X.xabort = A.xabort;
   X.dead = false;
+  X.flag = false;
+  if (fresh) { // is the start primal feasible?
+    const double tolb = A.tol_bnd;
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+      if (ii[u] <= m) {
+        if (lb[u] > -INFINITY && be[u] < lb[u] - tolb * (1.0 + fabs(lb[u]))) X.flag = true;
+        if (ub[u] < INFINITY && be[u] > ub[u] + tolb * (1.0 + fabs(ub[u]))) X.flag = true;
+      }
+    }
+  }
 #define HS(S, U) hist[((size_t)(S) * (CPT + RPT) + (U)) * 256 + t]
 #define HC(S, U) hist[((size_t)(S) * (CPT + RPT) + CPT + (U)) * 256 + t]
   int g = 0, used = 0;
@@ -2305,22 +2345,38 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
   } while (0)
   PRICE();
   Cand qc = xchg<0, 5>(X, pc, pp, po, s_slots, s_pay);
+  if (boot && !X.dead) {
+    if (X.flag) { // not primal feasible: the generic step decides between the dual simplex and phase 1
+      if (lead) c->fstate = F_OFF;
+      return;
+    }
+    if (lead) {
+      c->fstate = F_RUN;
+      c->step = ST_NONE;
+    }
+  }
+  X.flag = false;
+  bool end_itlim = false;
   for (;;) {
     if (X.dead) break;
     const int q = qc.idx;
     const bool none = (q == 0);
     const int left = (budget < 0) ? 1 : budget - used;
     if (none || left <= 0 || stall >= A.stall_limit) {
-      if (lead && g == 0) {
-        c->fstate = F_STOP;
-        c->phase = PH_PRIMAL2;
-        // the pivot limit with an entering column still on offer and nothing perturbed is what the generic step would
-        // report as it stands (select_step: price, then `budget == 0` -> D_ITLIM)
-        if (!none && left <= 0 && stall < A.stall_limit && !perturbed) {
-          c->done = D_ITLIM;
-          c->step = ST_NONE;
+      // the pivot limit with an entering column still on offer and nothing perturbed is what the generic step would
+      // report as it stands (select_step: price, then `budget == 0` -> D_ITLIM)
+      const bool itlim = (!none && left <= 0 && stall < A.stall_limit && !perturbed);
+      if (g == 0) {
+        if (lead) {
+          c->fstate = F_STOP;
+          c->phase = PH_PRIMAL2;
+          if (itlim) {
+            c->done = D_ITLIM;
+            c->step = ST_NONE;
+          }
         }
-      }
+      } else
+        end_itlim = itlim; // once the chain is applied: the generic step that closes the batch says so (pc_itlim)
       break;
     }
     if (g >= kmax) break;
@@ -2403,6 +2459,13 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
     CH_STAMP(3);
     const int p = pw.idx, p_up = pw.aux;
     const double tstep = pw.k1, piv = ro[0], bp = ro[1], plb = ro[2], pub = ro[3];
+    // row p of this thread's columns and the entries of the earlier pivot columns in row p: requested as soon as p is
+    // known, ahead of the arithmetic of the decision (a bound flip does not use them)
+    double val[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; u++) val[u] = T[(size_t)p * ld + ((jj[u] <= n) ? jj[u] : n)];
+    double rcp_l = 0.0;
+    if (lane < g) rcp_l = ld_sc1(A.colq0 + (size_t)lane * A.cstride + p);
     bool flip = false;
     double tf = 0.0;
     if (lbq > -INFINITY && ubq < INFINITY && fq != MVX_NF) {
@@ -2448,13 +2511,10 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
         } else
           be[u] = fma(-a[u], s0, be[u]);
       }
-      // ---- row phase: row p of this thread's columns, the entries of the earlier pivot columns in row p
-      double val[CPT];
-#pragma unroll
-      for (int u = 0; u < CPT; u++) val[u] = T[(size_t)p * ld + ((jj[u] <= n) ? jj[u] : n)];
+      // ---- row phase
       CH_STAMP(4);
       if (lane < g) {
-        const double rcp = ld_sc1(A.colq0 + (size_t)lane * A.cstride + p);
+        const double rcp = rcp_l;
         s_wv[wave][0][lane] = rcp;
         s_wv[wave][1][lane] = xdiv(rcp, s_piv[lane]);
       }
@@ -2568,6 +2628,16 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
     return;
   }
   // ---- the chain is complete: the column side as the last step leaves it, where the bulk pass looks for it
+  if (g == 0 && fresh) { // no step (optimum, pivot limit, unbounded ray): nothing will write the restarted weights back,
+                         // and the generic step that settles the matter prices with them
+#pragma unroll
+    for (int u = 0; u < CPT; u++) {
+      if (jj[u] <= n) {
+        A.pw[0][jj[u]] = 1.0;
+        A.pw[1][jj[u]] = 1.0;
+      }
+    }
+  }
   if (g > 0) {
     const int xf = g & 1;
 #pragma unroll
@@ -2584,7 +2654,10 @@ __global__ __launch_bounds__(256) void k_chain(const ChainArgs A) {
   }
   if (lead) {
     c->pc_n = g;
-    if (g > 0) c->phase = PH_PRIMAL2;
+    if (g > 0) {
+      c->phase = PH_PRIMAL2;
+      c->pc_itlim = end_itlim ? 1 : 0;
+    }
   }
 }
 

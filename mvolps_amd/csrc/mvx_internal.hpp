@@ -129,6 +129,8 @@ struct Ctl {
   int hd_q[KCH], hd_sdir[KCH], hd_fq[KCH]; // the entering column of step l as k_pc found it: column, direction, status,
   double hd_dq[KCH], hd_wq[KCH], hd_lbq[KCH], hd_ubq[KCH]; // reduced cost, weight, bounds
   double ch_delta[KCH]; // bound flips: the entering variable's move
+  int pc_itlim;         // k_chain: the pivot limit is reached once the pending chain is applied and an entering column is still
+                        // on offer: the generic step that closes the batch reports it without pricing again
   int cl_abort;         // k_chain gave up waiting for its peer workgroups: the chain was dropped, nothing was changed
   unsigned long long *dbg; // diagnostic phase stamps of k_fcs (MVX_FCS_DBG=1), nullptr otherwise
 };
@@ -164,6 +166,7 @@ struct ChainArgs {
   int xg_bytes;
   unsigned tagbase;
   int nw, kmax;
+  int boot; // first chain launch of a batch: k_chain does what k_pboot does for k_pc / k_pr (feasibility of the start, fresh weights)
   int *xabort;
 };
 

@@ -1,8 +1,11 @@
-"""GPU: the chained primal path (k_fa + k_fcc/k_fcr per further step + ONE bulk launch k_fbc for the whole chain) leaves
-the same bits as the oracle, whatever the chain length: the pivots after the first are chosen from column / row slices
-carried through the earlier pivots of the chain entry by entry, so every case of that carry (pivot row, pivot column,
-the same row leaving twice, a column re-entering, bounds and status moved by the earlier swaps) has to come out as the
-bulk update would have left it.  Small LPs, resident-tableau kernel off, chain length forced."""
+"""GPU: the chained primal path (a chain's steps chosen by k_chain -- one launch, a cluster of resident workgroups --
+or by k_pc / k_pr, two launches per step; ONE bulk pass k_fbc3 + k_fpatch for the whole chain) leaves the same bits as
+the oracle, whatever the chain length and whoever chooses: the pivots after the first are chosen from column / row
+slices carried through the earlier pivots of the chain entry by entry, so every case of that carry (pivot row, pivot
+column, the same row leaving twice, a column re-entering, bounds and status moved by the earlier swaps) has to come out
+as the bulk update would have left it.  Small LPs, resident-tableau kernel off, chain length forced; every case is
+solved twice, the second time on the slab the first one gave back (a race inside a kernel shows as a difference between
+two runs long before it shows against the oracle)."""
 import numpy as np
 import pytest
 
@@ -14,12 +17,32 @@ from .test_gpu_parity import assert_same_state
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def chained(gpu):
+@pytest.fixture(params=[1, 0], ids=["cluster", "two-launch"])
+def chained(gpu, request):
+    """Both ways of choosing a chain's steps: k_chain (default) and k_pc / k_pr."""
     gpu.set_persist(0)
+    gpu.set_cluster(request.param)
     yield gpu
     gpu.set_chain(0)
+    gpu.set_cluster(1)
     gpu.set_persist(1)
+
+
+def cluster_counts(api):
+    import ctypes as C
+
+    a, b = C.c_longlong(0), C.c_longlong(0)
+    api.cluster_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def twice(api, load, check):
+    """The same problem on a fresh handle, and again on the slab that handle has given back by then."""
+    for rep in range(2):
+        P = load(api)
+        P.rc = P.simplex()
+        check(rep, P)
+        del P  # the last reference: the handle is deleted, its slab goes back to the cache
 
 
 @pytest.mark.parametrize("chain", [2, 5, 16])
@@ -27,11 +50,20 @@ def test_dense_lps_full_solves(chained, orc, chain):
     chained.set_chain(chain)
     for (m, n, seed) in ((64, 128, 1), (100, 37, 5), (256, 512, 12345), (300, 700, 11), (512, 1024, 12345)):
         A, b, c = synth.dense_lp(m, n, seed)
-        g, o = chained.create(), orc.create()
-        for P in (g, o):
+
+        def load(api):
+            P = api.create()
             P.load_dense(A, b, c)
-            assert P.simplex() == 0
-        assert_same_state(g, o, "dense %dx%d chain %d" % (m, n, chain))
+            return P
+
+        o = load(orc)
+        assert o.simplex() == 0
+
+        def check(rep, g):
+            assert g.rc == 0
+            assert_same_state(g, o, "dense %dx%d chain %d run %d" % (m, n, chain, rep))
+
+        twice(chained, load, check)
 
 
 @pytest.mark.parametrize("chain", [2, 3, 16])
@@ -44,12 +76,20 @@ def test_bounded_columns_bring_flips_into_the_chains(chained, orc, chain):
         A, b, c = synth.dense_lp(m, n, seed)
         col_b = [(capi.DB, 0.0, float(rng.integers(1, 4)) / 2) if j % 3 else (capi.LO, 0.0, 0.0) for j in range(n)]
         row_b = [(capi.UP, 0.0, float(v)) for v in b]
-        g, o = chained.create(), orc.create()
-        for P in (g, o):
+
+        def load(api):
+            P = api.create()
             P.load_general(A, row_b, col_b, c, direction=capi.MAX)
-            P.rc = P.simplex()
-        assert g.rc == o.rc
-        assert_same_state(g, o, "boxed %dx%d chain %d" % (m, n, chain))
+            return P
+
+        o = load(orc)
+        o.rc = o.simplex()
+
+        def check(rep, g):
+            assert g.rc == o.rc
+            assert_same_state(g, o, "boxed %dx%d chain %d run %d" % (m, n, chain, rep))
+
+        twice(chained, load, check)
 
 
 @pytest.mark.parametrize("chain", [2, 7, 16])
@@ -79,12 +119,15 @@ def test_degenerate_lps_and_stalling(chained, orc, chain):
     for case in ((358, 124, 41004, 0.8), (288, 252, 41002, 0.8), (314, 433, 41000, 0.95)):
         m, n, seed, dens = case
         A, b, c = lpgen.degenerate_lp(m, n, seed, frac0=dens)
-        g, o = lpgen.load_degenerate(chained, A, b, c), lpgen.load_degenerate(orc, A, b, c)
-        for P in (g, o):
-            P.rc = P.simplex()
-        assert g.rc == o.rc
-        assert g.pert_cnt == o.pert_cnt and g.bland_cnt == o.bland_cnt
-        assert_same_state(g, o, "degenerate %s chain %d" % (case, chain))
+        o = lpgen.load_degenerate(orc, A, b, c)
+        o.rc = o.simplex()
+
+        def check(rep, g):
+            assert g.rc == o.rc
+            assert g.pert_cnt == o.pert_cnt and g.bland_cnt == o.bland_cnt
+            assert_same_state(g, o, "degenerate %s chain %d run %d" % (case, chain, rep))
+
+        twice(chained, lambda api: lpgen.load_degenerate(api, A, b, c), check)
     for name, (A, b, c) in lpgen.CYCLING.items():
         A, b, c = (np.array(v, float) for v in (A, b, c))
         g, o = chained.create(), orc.create()
@@ -92,6 +135,43 @@ def test_degenerate_lps_and_stalling(chained, orc, chain):
             P.load_dense(A, b, c)
             assert P.simplex() == 0
         assert_same_state(g, o, name)
+
+
+def test_cluster_launches_are_counted_and_none_gives_up(gpu, orc):
+    """The default path is the cluster kernel: launches are made, none aborts (an abort would silently move the rest
+    of the process to k_pc / k_pr)."""
+    gpu.set_persist(0)
+    gpu.set_cluster(1)
+    try:
+        before = cluster_counts(gpu)
+        A, b, c = synth.dense_lp(300, 700, 3)
+        g, o = gpu.create(), orc.create()
+        for P in (g, o):
+            P.load_dense(A, b, c)
+            assert P.simplex() == 0
+        assert_same_state(g, o, "300x700")
+        after = cluster_counts(gpu)
+        assert after[0] > before[0], "no k_chain launch was made"
+        assert after[1] == before[1], "a k_chain launch gave up waiting for its peers"
+    finally:
+        gpu.set_persist(1)
+
+
+@pytest.mark.parametrize("m,n,seed,lim", [(40, 9000, 4, 120), (9000, 60, 6, 60), (8300, 8400, 2, 70)])
+def test_wide_cluster_geometry(gpu, orc, m, n, seed, lim):
+    """More than 8192 columns or rows: two columns / rows to a thread of k_chain (the CPT = RPT = 2 kernel), chains as
+    long as its LDS holds."""
+    gpu.set_cluster(1)
+    before = cluster_counts(gpu)
+    A, b, c = synth.dense_lp(m, n, seed)
+    g, o = gpu.create(), orc.create()
+    for P in (g, o):
+        P.load_dense(A, b, c)
+        P.rc = P.simplex(it_lim=lim)
+    assert g.rc == o.rc
+    assert_same_state(g, o, "%dx%d, %d pivots" % (m, n, lim))
+    after = cluster_counts(gpu)
+    assert after[0] > before[0] and after[1] == before[1]
 
 
 def test_chain_length_by_size_is_the_default(gpu, orc):
