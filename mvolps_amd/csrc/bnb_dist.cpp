@@ -128,6 +128,8 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
   std::map<long long, std::vector<int>> win_load; // absolute window number -> nodes per rank already placed in it
   mvx_dist_stats stats{0, 0, 0, 0};
   int rc = 0;
+  int late_err = 0; // a failure one rank met AFTER an exchange (unpacking an image): it rides in the next round's first
+                    // all-reduce (or in one of its own behind the loop), so that every rank stops in the same place
 
   auto drop = [&](int oid) {
     auto it = local.find(oid);
@@ -145,8 +147,9 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
     const int W = (int)std::min<long long>((long long)queue.size(), W_full);
 
     // ---- A. solve the window (bs.cpp:114-117, printInfo bs.cpp:135|151)
-    std::vector<double> A((size_t)W * 6, NEG_INF);
-    {
+    std::vector<double> A((size_t)W * 6 + 1, NEG_INF); // last entry: a rank carries a failure from the last round
+    A[(size_t)W * 6] = (double)late_err;
+    if (!late_err) {
       // bs.cpp:114-116 copies the node's problem into a scratch and solves the copy; the node is discarded after
       // this round either way, so its own clone is solved in place
       std::vector<void *> hs;
@@ -174,6 +177,10 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
       }
     }
     if ((rc = allreduce_max(A)) != 0) break;
+    if (A[(size_t)W * 6] > 0.0) {
+      rc = MVX_EFAIL;
+      break;
+    }
 
     // ---- B. replay the serial decisions in queue order
     std::vector<Branch> branch_list;
@@ -285,7 +292,10 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
         }
       }
     }
-    if ((rc = allreduce_max(Cv)) != 0) break;
+    if ((rc = allreduce_max(Cv)) != 0) {
+      for (auto &kv : fresh) api->delete_prob(kv.second);
+      break;
+    }
     if (Cv[nb * 4] == 1.0) {
       for (auto &kv : fresh) api->delete_prob(kv.second);
       rc = MVX_EDIST_NOCUT;
@@ -336,10 +346,12 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
       }
     }
     std::vector<mvx_xfer> sends, recvs;
-    std::vector<int> recv_oid;
+    std::vector<int> recv_oid, send_oid;
     std::vector<std::pair<size_t, Ev>> cand;
-    long long kid_no = 0;
-    for (size_t k = 0; k < nb && rc == 0; k++) {
+    long long kid_no = 0, moved_this_round = 0;
+    int lerr = 0; // a failure that only this rank sees (device memory for an image, pack): agreed on below, before any
+                  // point-to-point transfer is posted -- a rank that walked away alone would leave its peers waiting
+    for (size_t k = 0; k < nb; k++) {
       const Branch &b = branch_list[k];
       const double *row = &Cv[k * 4];
       const double ub[2] = {row[0], row[1]};
@@ -358,21 +370,42 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
         if (owner != b.owner) {
           stats.migrated++;
           stats.migrated_bytes += (long long)nbytes;
+          moved_this_round++;
         }
         if (b.owner == rank && owner == rank) {
           local[oid] = fresh.at(oid);
+          fresh.erase(oid);
         } else if (b.owner == rank) {
-          void *buf = img->buf_alloc(nbytes);
-          if (!buf || img->pack(fresh.at(oid), root, buf) != 0) rc = MVX_EFAIL;
+          void *buf = lerr ? nullptr : img->buf_alloc(nbytes);
+          if (!buf || img->pack(fresh.at(oid), root, buf) != 0) lerr = 1;
           sends.push_back(mvx_xfer{buf, nbytes, owner});
-          api->delete_prob(fresh.at(oid));
+          send_oid.push_back(oid);
         } else if (owner == rank) {
-          void *buf = img->buf_alloc(nbytes);
-          if (!buf) rc = MVX_EFAIL;
+          void *buf = lerr ? nullptr : img->buf_alloc(nbytes);
+          if (!buf) lerr = 1;
           recvs.push_back(mvx_xfer{buf, nbytes, b.owner});
           recv_oid.push_back(oid);
         }
       }
+    }
+    // every rank knows the whole dealing, so every rank knows whether this round moves a child at all: only then is
+    // there anything to agree on
+    if (world > 1 && moved_this_round > 0) {
+      std::vector<double> E(1, (double)lerr);
+      const int arc = allreduce_max(E);
+      if (arc != 0) rc = arc;
+      else if (E[0] != 0.0) rc = MVX_EFAIL; // the same code on every rank, and nobody enters the exchange
+    } else if (lerr)
+      rc = MVX_EFAIL;
+    if (rc != 0) {
+      for (auto &x : sends) if (x.buf) img->buf_free(x.buf);
+      for (auto &x : recvs) if (x.buf) img->buf_free(x.buf);
+      for (auto &kv : fresh) api->delete_prob(kv.second); // the children not handed to `local` yet
+      break;
+    }
+    for (int oid : send_oid) { // packed: the image travels, the handle goes
+      api->delete_prob(fresh.at(oid));
+      fresh.erase(oid);
     }
     // candidate events go right behind their node's branched event (bs.cpp:300-318 emits them inside the node's
     // iteration): splice from the back so that earlier positions stay valid
@@ -380,9 +413,9 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
     if (rc == 0 && world > 1 && (!sends.empty() || !recvs.empty()))
       rc = comm->exchange(comm->ctx, sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size());
     for (size_t i = 0; i < recvs.size(); i++) {
-      if (rc == 0) {
+      if (rc == 0 && !late_err) {
         void *q = api->create_prob();
-        if (img->unpack(q, root, recvs[i].buf) != 0) rc = MVX_EFAIL;
+        if (img->unpack(q, root, recvs[i].buf) != 0) late_err = 1; // this rank only: agreed on at the next all-reduce
         local[recv_oid[i]] = q;
       }
       img->buf_free(recvs[i].buf);
@@ -398,6 +431,12 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
     for (auto it = x_keep.begin(); it != x_keep.end();) it = (it->first != inc_oid) ? x_keep.erase(it) : std::next(it);
   }
 
+  if (rc == 0 && world > 1) { // a failure behind the last exchange has had no all-reduce to ride on yet
+    std::vector<double> E(1, (double)late_err);
+    rc = allreduce_max(E);
+    if (rc == 0 && E[0] > 0.0) rc = MVX_EFAIL;
+  } else if (rc == 0 && late_err)
+    rc = MVX_EFAIL;
   for (auto &kv : local) api->delete_prob(kv.second);
   local.clear();
   if (rc != 0) return rc;

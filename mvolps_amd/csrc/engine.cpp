@@ -1424,6 +1424,10 @@ static int after_solve(mvx_prob *P, const mvx_smcp *parm, int rc, int pivots) {
     P->piv_since_check = 0;
     if (row_residual_sample(P, REFRESH_SAMPLE_ROWS) > g_refresh_tol && refresh_tableau(P)) {
       const int before = P->it_cnt;
+      // the rebuilt tableau has not been looked at by anything yet: the simplex runs on it whatever the status says (the
+      // oracle's simplex_once has no "already solved" shortcut) -- it may be infeasible or non-optimal beyond the
+      // tolerance, or a numerically singular column may have been skipped
+      P->status = MVX_UNDEF;
       rc = solve_once(P, parm, true); // the pivot limit of the call, if any, applies to this leg afresh
       P->piv_since_check += P->it_cnt - before;
     }

@@ -82,6 +82,25 @@ def test_device_refresh_is_bit_exact_with_the_oracle(gpu, orc, forced, shape):
 
 
 @pytest.mark.gpu
+def test_the_simplex_runs_again_on_the_rebuilt_tableau(gpu, orc, forced):
+    """After a refresh the device runs the simplex on the rebuilt tableau, as the oracle does (no "already optimal"
+    shortcut: a rebuilt tableau may be off by more than the tolerance): the leg leaves a device time behind, and with
+    zero tolerances -- where rounding noise of the rebuild decides whether pivots follow -- the device still equals the
+    oracle bit for bit."""
+    forced(gpu)
+    tol = (0.0, 0.0, 1e-9)
+    for k, (m, n) in enumerate(((30, 50), (60, 90), (40, 120), (96, 160))):
+        A, b, c = lpgen.degenerate_lp(m, n, 4100 + k, frac0=0.8)
+        g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+        rcs = [P.simplex(tol=tol) for P in (g, o)]
+        assert rcs[0] == rcs[1] and g.status == o.status
+        assert gpu.get_refresh_cnt(g.h) == orc.get_refresh_cnt(o.h)
+        assert g.it_cnt == o.it_cnt and np.array_equal(g.tableau(), o.tableau())
+        if gpu.get_refresh_cnt(g.h) and g.status == capi.OPT:
+            assert gpu.last_solve_ms(g.h) > 0.0, "the leg after the refresh never reached the device"
+
+
+@pytest.mark.gpu
 def test_bnb_with_forced_refreshes_on_the_device(gpu, orc, forced):
     """Refreshes inside batched child solves (window driver, device work queue) and after migration-free clones."""
     from oracle import oracle
