@@ -83,9 +83,16 @@ int rccl_exchange(void *ctx, const mvx_xfer *sends, int ns, const mvx_xfer *recv
   if (ns == 0 && nr == 0) return 0;
   RC_HIP(hipSetDevice(c->dev));
   RC_NCCL(ncclGroupStart());
-  for (int k = 0; k < ns; k++) RC_NCCL(ncclSend(sends[k].buf, sends[k].bytes, ncclUint8, sends[k].peer, c->comm, c->stream));
-  for (int k = 0; k < nr; k++) RC_NCCL(ncclRecv(recvs[k].buf, recvs[k].bytes, ncclUint8, recvs[k].peer, c->comm, c->stream));
-  RC_NCCL(ncclGroupEnd());
+  // a failing send / receive must not leave the communicator inside an open group: note the first error, close the
+  // group whatever happened, then report
+  ncclResult_t first = ncclSuccess;
+  for (int k = 0; k < ns && first == ncclSuccess; k++) first = ncclSend(sends[k].buf, sends[k].bytes, ncclUint8, sends[k].peer, c->comm, c->stream);
+  for (int k = 0; k < nr && first == ncclSuccess; k++) first = ncclRecv(recvs[k].buf, recvs[k].bytes, ncclUint8, recvs[k].peer, c->comm, c->stream);
+  const ncclResult_t closed = ncclGroupEnd();
+  if (first != ncclSuccess || closed != ncclSuccess) {
+    std::fprintf(stderr, "mvx rccl: exchange failed: %s\n", ncclGetErrorString(first != ncclSuccess ? first : closed));
+    return 0x302;
+  }
   RC_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -105,11 +112,21 @@ extern "C" int mvx_rccl_comm_create(const void *id, int rank, int size, mvx_comm
   std::memset(out, 0, sizeof(*out));
   RcclCtx *c = new (std::nothrow) RcclCtx();
   if (!c) return 0x301;
-  RC_HIP(hipGetDevice(&c->dev));
-  RC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  // nothing of a half-built context is left behind
+  auto fail = [&](int code, const char *what) {
+    std::fprintf(stderr, "mvx rccl: %s failed\n", what);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return code;
+  };
+  if (hipGetDevice(&c->dev) != hipSuccess) return fail(0x301, "hipGetDevice");
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    c->stream = nullptr;
+    return fail(0x301, "hipStreamCreateWithFlags");
+  }
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof(u));
-  RC_NCCL(ncclCommInitRank(&c->comm, size, u, rank));
+  if (ncclCommInitRank(&c->comm, size, u, rank) != ncclSuccess) return fail(0x302, "ncclCommInitRank");
   out->ctx = c;
   out->rank = rank;
   out->size = size;

@@ -849,9 +849,9 @@ static void flush_update_events(Context &c, size_t used) {
 // can be in flight on different streams (engine_simplex_batch): begin -> {enqueue, sync, collect}*.
 // ---- resident-tableau path (k_persist): which problems take it, its buffers, backup and restore
 constexpr int PERSIST_HEAD_STRIDE_MAX = 4; // granules between two strips' heads
-static int g_persist_mode = -1;      // -1: environment MVX_PERSIST (default on), 0 off, 1 on
-static bool g_persist_broken = false; // a launch aborted (its workgroups were not co-resident in time): off for good
-static long long g_persist_launches = 0, g_persist_aborts = 0;
+static std::atomic<int> g_persist_mode{-1}; // -1: environment MVX_PERSIST (default on), 0 off, 1 on
+static std::atomic<bool> g_persist_broken{false}; // a launch aborted (its workgroups were not co-resident in time): off for good
+static std::atomic<long long> g_persist_launches{0}, g_persist_aborts{0};
 struct PersistPlan {
   int cpw = 0, nw = 0;
   size_t lds = 0;
@@ -1002,7 +1002,10 @@ static void job_begin(Context &c, SolveJob &J) {
     a.xg = sc.d_xg; a.xg_bytes = (int)XG_BYTES; a.xabort = sc.d_xabort;
     a.nw = chain_cluster_nw(P->m, P->n); a.kmax = 0; a.tagbase = 0; a.boot = 0;
   }
-  J.cluster = cluster_wanted() && chain_cluster_kmax(P->m, P->n) > 0;
+  // k_chain and k_persist need their workgroups resident together: two such launches from two host threads (the main
+  // context and a B&B worker's) could each hold half of the CUs they both need and wait for the rest until they time
+  // out.  Only the main context, whose calls are serialised, uses them; the others take the plain kernels.
+  J.cluster = (J.sc == &c.main) && cluster_wanted() && chain_cluster_kmax(P->m, P->n) > 0;
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   J.chain = J.chain0 = h->chain_max;
   J.try_dfused = P->hint_dual && dual_fused_worth_it(P);
@@ -1057,7 +1060,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
   auto body = [&](int m_grid) {
     if (J.try_fused) {
       PersistPlan pl;
-      if (depth > 0 && !J.profiled && persist_plan(c, P, &pl) && ensure_persist(c, sc, P, pl)) {
+      if (depth > 0 && !J.profiled && J.sc == &c.main && persist_plan(c, P, &pl) && ensure_persist(c, sc, P, pl)) {
         // cache-resident size: one generic step settles the phase, then the whole run of primal pivots in ONE launch
         // with the tableau held in LDS.  In front of it a backup (slab, control block, both devex weight sets): a
         // launch whose workgroups do not all become resident in time aborts mid-step, and the backup is what the

@@ -15,12 +15,11 @@ lib = mvolps_amd.load_library()
 lib.mvx_fcs_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
 buf = (C.c_ulonglong * (32 * 16))()
 rows = lib.mvx_fcs_debug_stamps(buf)
-names = ["gather+carry", "ratio", "xchg C", "decide+rows", "row load", "row carry", "row step", "price", "xchg R"]
+names = ["gather+carry", "ratio", "xchg C", "decide+rows", "row carry", "row step", "price", "xchg R"]
 print("step  " + " ".join("%12s" % x for x in names) + "        total (us)")
 for g in range(rows):
     a = [buf[g * 16 + k] for k in range(9)]
     if a[0] == 0 or a[8] == 0:
         continue
     da = [(a[k + 1] - a[k]) / 100.0 for k in range(8)]
-    nxt = buf[(g + 1) * 16] if g + 1 < rows else 0
     print("%4d  %s  %12.2f" % (g, " ".join("%12.2f" % x for x in da), (a[8] - a[0]) / 100.0))

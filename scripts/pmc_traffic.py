@@ -3,15 +3,18 @@
 Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in
 KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read
 (16 B per lane), so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
-usage: pmc_traffic.py <fetch_dir> <write_dir> <m> <n> <out.json>
+usage: pmc_traffic.py <fetch_dir> <write_dir> <m> <n> <out.json> [kernel-name substring, default k_fb]
 """
 import csv, glob, json, statistics, sys
 
+KERNEL = sys.argv[6] if len(sys.argv) > 6 else "k_fb"
+
+
 def per_launch(d, counter):
-    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
+    f = (glob.glob(d + "/**/*counter_collection.csv", recursive=True))[0]
     vals = []
     for r in csv.DictReader(open(f)):
-        if "k_fb" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
             vals.append(float(r["Counter_Value"]))
     # steady state: drop the bootstrap (gather-only) launches, which move almost nothing
     big = [v for v in vals if v > 0.5 * max(vals)]
@@ -22,7 +25,7 @@ write_kb, nw = per_launch(sys.argv[2], "WRITE_SIZE")
 m, n = int(sys.argv[3]), int(sys.argv[4])
 alg = 16 * (m + 1) * (n + 1)
 out = {
-    "m": m, "n": n, "kernel": "k_fb",
+    "m": m, "n": n, "kernel": KERNEL,
     "FETCH_SIZE_KiB_median": fetch_kb, "WRITE_SIZE_KiB_median": write_kb, "launches": [nf, nw],
     "read_bytes": 2.0 * fetch_kb * 1024.0, "write_bytes": write_kb * 1024.0,
     "bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
