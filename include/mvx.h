@@ -151,6 +151,11 @@ const char *mvx_version(void);   /* glp_version  util.cpp:278 */
    right-hand side and positional back-substitution included; 1: mvx_generateCutGMI's.  Bit-identical to the
    one-column host functions of mvx_bnb.h.  Returns 0, -1 on bad arguments, -2 when the device is out of memory */
 int mvx_gmi_cuts(const mvx_prob *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok);
+/* The same for cuts taken from DIFFERENT solved handles in one call: cut t comes from Ps[t], column cols[t].  The handles
+   must share their columns and their first model rows (clones of one root, each with its own bounds, basis and appended
+   cut rows): a round of a B&B window takes one cut from each of its branching nodes (bs.cpp:249-258 run for 64 nodes at
+   once).  vals is count x (n+1).  Returns -3 when the handles do not share a root (call mvx_gmi_cuts per handle then). */
+int mvx_gmi_cuts_many(const mvx_prob *const *Ps, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok);
 
 /* ---- engine-state access (parity tests, visualisers) --------------------------- */
 int mvx_get_tableau_ld(const mvx_prob *P);

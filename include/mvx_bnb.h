@@ -61,6 +61,9 @@ typedef struct mvx_lp_api {
      one call (mvx_gmi_cuts: tableau rows, coefficient formula and back-substitution on the device); the driver then
      generates a node's cuts through it instead of one eval_tab_row + m get_mat_row calls per cut */
   int (*gmi_cuts)(const void *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok);
+  /* optional (may be NULL): one cut from each of `count` different solved handles (mvx_gmi_cuts_many): the window driver
+     generates the cuts of a whole round through it */
+  int (*gmi_cuts_many)(const void *const *Ps, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok);
 } mvx_lp_api;
 
 const mvx_lp_api *mvx_hip_lp_api(void);

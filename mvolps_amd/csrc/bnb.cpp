@@ -429,11 +429,66 @@ static bool gmi_candidate(const mvx_lp_api *api, const void *a, int j) {
   return !(f0 < 1e-6 || f0 > 1.0 - 1e-6);
 }
 
+// The lazy cut modes generate ONE cut per branching node (cut.cpp:20 only ever appends the last one): a window of 64
+// nodes means 64 tableau-row reads and 64 O(m n) back-substitutions on the host, one node after the other, while the
+// device idles -- that loop, not the LP solves, bounded the cut path (1.7 k nodes/s against 15 k without cuts).  Here the
+// cuts of a whole round are made in one device pass (mvx_lp_api.gmi_cuts_many): for every node of the window that
+// may branch, the column the host loop would settle on -- bug-compatible: the last basic integer column (gmi.cpp:18-27);
+// repaired: the last column generateCutGMI would not reject out of hand -- and one launch pair for all of them.  Same
+// bits as generateCut3 / generateCutGMI (tests/test_gpu_gmi.py); a node whose cut the engine rejects (ok = 0, zero
+// norm) gets nullptr and goes through the host loop as before.
+static std::vector<std::unique_ptr<CutContainer>> round_cuts(const mvx_lp_api *api, const std::vector<void *> &nodes, const std::vector<char> &wanted,
+                                                              const mvx_bnb_params &prm, bool quirks) {
+  std::vector<std::unique_ptr<CutContainer>> out(nodes.size());
+  if (!api->gmi_cuts_many || prm.cut_strat == 0 || !prm.lazy_pool || (!quirks && prm.cut_select != 0)) return out;
+  std::vector<const void *> ps;
+  std::vector<int> cols;
+  std::vector<size_t> slot;
+  for (size_t w = 0; w < nodes.size(); w++) {
+    if (!wanted[w]) continue;
+    const void *a = nodes[w];
+    const int na = api->get_num_cols(a);
+    for (int j = na; j >= 1; j--) {
+      const bool cand = quirks ? (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) : gmi_candidate(api, a, j);
+      if (cand) {
+        ps.push_back(a);
+        cols.push_back(j);
+        slot.push_back(w);
+        break;
+      }
+    }
+  }
+  const int k = (int)ps.size();
+  if (k < 2) return out; // a single cut: the host loop is as fast
+  const int n = api->get_num_cols(ps[0]);
+  std::vector<double> vals((size_t)k * (n + 1)), rhs((size_t)k);
+  std::vector<int> ok((size_t)k, 0);
+  if (api->gmi_cuts_many(ps.data(), quirks ? 0 : 1, cols.data(), k, vals.data(), rhs.data(), ok.data()) != 0) return out;
+  for (int t = 0; t < k; t++) {
+    if (!ok[(size_t)t]) continue;
+    const double *v = &vals[(size_t)t * (n + 1)];
+    if (!quirks) { // generateCutGMI rejects a cut without coefficients
+      double nrm = 0.0;
+      for (int j = 1; j <= n; j++) nrm += v[j] * v[j];
+      if (!(nrm > 0.0)) continue;
+    }
+    auto c = std::make_unique<CutContainer>();
+    c->inds.resize((size_t)n + 1);
+    c->vals.assign(v, v + n + 1);
+    for (int j = 0; j <= n; j++) c->inds[(size_t)j] = j;
+    c->lb = rhs[(size_t)t];
+    c->oid = 0;
+    out[slot[(size_t)t]] = std::move(c);
+  }
+  return out;
+}
+
 // Cut step of a branching node (bs.cpp:249-258), shared by both drivers: bug-compatible mode feeds the
 // persistent pool and appends its last cut (cut.cpp:16-21); repaired mode appends this node's own GMI cuts,
 // chosen by cut_select / -cf.
 // Returns the number of rows appended; -1 when the bug-compatible path found its pool empty (nothing generated yet).
-static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &prm, bool quirks, CutPool &pool) {
+// `pre`: the one cut the lazy modes would generate for this node, already made by round_cuts (nullptr: make it here).
+static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &prm, bool quirks, CutPool &pool, const CutContainer *pre = nullptr) {
   if (prm.cut_strat == 0) return 0;
   const int na = api->get_num_cols(a);
   const bool dev = api->gmi_cuts != nullptr;
@@ -443,7 +498,7 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
       for (int j = na; j >= 1; j--) {
         if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) {
           // one cut: the host loop (one row read, one back-substitution) is as fast as a device pass with its set-up
-          pool.replaceLast(generateCut3(api, a, j));
+          pool.replaceLast(pre ? *pre : generateCut3(api, a, j));
           break;
         }
       }
@@ -464,7 +519,10 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
   }
   std::vector<CutContainer> local;
   std::vector<double> eff;
-  if (prm.cut_select == 0 && prm.lazy_pool) {
+  if (prm.cut_select == 0 && prm.lazy_pool && pre) {
+    local.push_back(*pre);
+    eff.push_back(0.0);
+  } else if (prm.cut_select == 0 && prm.lazy_pool) {
     // only the last cut generated would be appended (cut.cpp:20): find it from the far end instead of
     // generating one cut per basic integer column (each is a tableau row read + an O(m n) back-substitution)
     for (int j = na; j >= 1 && local.empty(); j--) {
@@ -714,7 +772,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
   if (const char *e = std::getenv("MVX_BNB_DEPTH")) depth = (size_t)std::max(1, std::min(4, std::atoi(e)));
   CutPool pool(api); // persistent across nodes in bug-compatible mode (cut.h:15-23)
   const bool timing = std::getenv("MVX_BNB_TIMING") != nullptr;
-  double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tWait = 0;
+  double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tB_cuts = 0, tWait = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
   // wait for a round's children, book their results, flush the round's events
@@ -782,6 +840,23 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     }
     if (!need.empty()) api->simplex_batch(need.data(), (int)need.size(), nullptr, nullptr); // none of them is in flight
     tA += now() - t0; t0 = now();
+    // the lazy cut modes: the one cut of every node of the window that may branch, in one device pass (round_cuts);
+    // printInfo of the window is taken ahead for that and reused by the replay
+    std::vector<std::pair<int, std::vector<int>>> info;
+    std::vector<std::unique_ptr<CutContainer>> pre;
+    if (prm.cut_strat != 0 && prm.lazy_pool && api->gmi_cuts_many && W > 1) {
+      info.resize(W);
+      std::vector<char> wanted(W, 0);
+      double ti = now();
+      for (size_t w = 0; w < W; w++) {
+        info[w] = printInfo(api, a[w], quirks);
+        wanted[w] = info[w].first == 0; // neither infeasible nor integral: branches unless its bound prunes it
+      }
+      tB_info += now() - ti;
+      ti = now();
+      pre = round_cuts(api, a, wanted, prm, quirks);
+      tB_cuts += now() - ti;
+    }
     // B. replay in queue order
     Round cur;
     cur.node_events.resize(W);
@@ -800,7 +875,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       processed++;
       rec.emit(MVX_EV_PREGNANT, node->oid, api->get_obj_val(aw), 0.0, 0, 0);
       double ti = now();
-      auto ret = printInfo(api, aw, quirks);
+      auto ret = info.empty() ? printInfo(api, aw, quirks) : std::move(info[w]);
       tB_info += now() - ti;
       const int status = ret.first;
       const std::vector<int> &vars = ret.second;
@@ -847,7 +922,9 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
           if (i != 0) acc += getFract(api->get_col_prim(aw, i));
         // cuts go onto the node's own problem (the serial driver's scratch copy `a`): both children inherit them.
         // The replay runs in queue order, so the persistent pool sees the nodes in bs.cpp's order.
-        add_node_cuts(api, aw, prm, quirks, pool);
+        ti = now();
+        add_node_cuts(api, aw, prm, quirks, pool, pre.empty() ? nullptr : pre[w].get());
+        tB_cuts += now() - ti;
         const int pick = params.pickVar(vars);
         rec.emit(MVX_EV_BRANCHED, node->oid, node->upperBound, acc, (int)vars.size(), pick);
         Branch br;
@@ -952,8 +1029,8 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
   }
   while (!flight.empty()) finalize_oldest();
   if (timing)
-    std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f)  waiting for child solves %.1f ms\n", tA * 1e3,
-                 tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tWait * 1e3);
+    std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f, cuts %.1f)  waiting for child solves %.1f ms\n", tA * 1e3,
+                 tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tB_cuts * 1e3, tWait * 1e3);
   leafContainer.clear();
   pack_result(res, rec, id, count, has_incumbent, bestLower, incumbent_oid, n0, xbest, hit_limit);
   return 0;
@@ -993,6 +1070,9 @@ const mvx_lp_api g_hip_api = {
     [](const void *P) { return mvx_get_obj_dir((const mvx_prob *)P); },
     [](const void *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
       return mvx_gmi_cuts((const mvx_prob *)P, repaired, cols, count, vals, rhs, ok);
+    },
+    [](const void *const *Ps, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
+      return mvx_gmi_cuts_many((const mvx_prob *const *)Ps, repaired, cols, count, vals, rhs, ok);
     },
 };
 

@@ -429,6 +429,9 @@ int mvx_get_basis(const mvx_prob *P, int *head, int *nb, int *flag) {
 int mvx_gmi_cuts(const mvx_prob *P, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
   return mvx::engine_gmi_cuts(P, repaired ? 1 : 0, cols, count, vals, rhs, ok);
 }
+int mvx_gmi_cuts_many(const mvx_prob *const *Ps, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
+  return mvx::engine_gmi_cuts_many(Ps, repaired ? 1 : 0, cols, count, vals, rhs, ok);
+}
 
 int mvx_device_count(void) { return mvx::device_count(); }
 int mvx_set_device(int dev) { return mvx::set_device(dev); }

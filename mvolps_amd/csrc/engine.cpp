@@ -109,6 +109,11 @@ struct SolveCtx {
   int *d_nflagk[2] = {};
   double *d_betab = nullptr, *d_ppart = nullptr, *d_rpart = nullptr;
   double *d_zeros = nullptr; // chained primal path: zeros (bound-flip operands of the bulk pass)
+  // row combinations queued without a host round trip each (cut rows of a B&B round): a ring of pinned staging slots
+  // (control block, row weights, base row); the stream is synchronised only when the ring wraps
+  unsigned char *rc_ring = nullptr;
+  size_t rc_slot_bytes = 0;
+  int rc_next = 0, rc_m_cap = 0, rc_ld = 0;
   // cluster selection (k_chain): exchange area, abort flag, tag of the next launch's first exchange
   unsigned *d_xg = nullptr;
   int *d_xabort = nullptr;
@@ -1791,21 +1796,43 @@ void engine_add_rows(mvx_prob *P, int first, int nrs) {
 }
 
 // run k_rowcomb with host-provided weights / base, writing row `dst_row` of the tableau
+constexpr int RC_SLOTS = 32;
 static void rowcomb_into_row(mvx_prob *P, const std::vector<double> &w, const std::vector<double> &base, int dst_row) {
   Context &c = ctx();
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
   flush_copies(c);
   ensure_scratch(sc, P->m_cap, P->ld);
-  HIPCHECK(hipStreamSynchronize(sc.stream)); // h_ctl / pageable sources below must not be in flight
-  fill_ctl(sc, P, sc.h_ctl);
-  sc.h_ctl->rc_base = sc.d_rcbase;
-  sc.h_ctl->rc_out = P->d_T + (size_t)dst_row * P->ld;
-  upload_ctl(sc);
-  HIPCHECK(hipMemcpyAsync(sc.d_wts, w.data(), (size_t)(P->m + 1) * 8, hipMemcpyHostToDevice, sc.stream));
-  HIPCHECK(hipMemcpyAsync(sc.d_rcbase, base.data(), (size_t)(P->n + 1) * 8, hipMemcpyHostToDevice, sc.stream));
+  // The operands go through a pinned slot of their own, so nothing here waits for the device: a B&B round appends one
+  // cut row to each of its branching nodes, and with a synchronisation in front of and behind every one of them the
+  // host paid ~100 us per node for 10 us of kernels.  Whoever reads the row next does so on this stream or
+  // synchronises it first (eval_tab_row, the clone launches, the batch entry).
+  if (!sc.rc_ring || P->m_cap > sc.rc_m_cap || P->ld > sc.rc_ld) {
+    HIPCHECK(hipStreamSynchronize(sc.stream));
+    if (sc.rc_ring) HIPCHECK(hipHostFree(sc.rc_ring));
+    sc.rc_m_cap = std::max(P->m_cap, sc.rc_m_cap);
+    sc.rc_ld = std::max(P->ld, sc.rc_ld);
+    sc.rc_slot_bytes = align_up(sizeof(Ctl), 256) + align_up((size_t)(sc.rc_m_cap + 1) * 8, 256) + align_up((size_t)sc.rc_ld * 8, 256);
+    HIPCHECK(hipHostMalloc((void **)&sc.rc_ring, sc.rc_slot_bytes * RC_SLOTS));
+    sc.rc_next = 0;
+  }
+  if (sc.rc_next == RC_SLOTS) { // every slot may still be in flight
+    HIPCHECK(hipStreamSynchronize(sc.stream));
+    sc.rc_next = 0;
+  }
+  unsigned char *slot = sc.rc_ring + sc.rc_slot_bytes * (size_t)sc.rc_next++;
+  Ctl *hc = (Ctl *)slot;
+  double *hw = (double *)(slot + align_up(sizeof(Ctl), 256));
+  double *hb = (double *)((unsigned char *)hw + align_up((size_t)(sc.rc_m_cap + 1) * 8, 256));
+  fill_ctl(sc, P, hc);
+  hc->rc_base = sc.d_rcbase;
+  hc->rc_out = P->d_T + (size_t)dst_row * P->ld;
+  std::memcpy(hw, w.data(), (size_t)(P->m + 1) * 8);
+  std::memcpy(hb, base.data(), (size_t)(P->n + 1) * 8);
+  HIPCHECK(hipMemcpyAsync(sc.d_ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(sc.d_wts, hw, (size_t)(P->m + 1) * 8, hipMemcpyHostToDevice, sc.stream));
+  HIPCHECK(hipMemcpyAsync(sc.d_rcbase, hb, (size_t)(P->n + 1) * 8, hipMemcpyHostToDevice, sc.stream));
   launch_rowcomb(sc.d_ctl, P->m, P->n, 0, sc.stream);
-  HIPCHECK(hipStreamSynchronize(sc.stream));
 }
 
 void engine_row_from_model(mvx_prob *P, int i) {
@@ -1996,31 +2023,52 @@ static bool dev_matrix_current(const mvx_prob *P) {
   return true;
 }
 
-// `count` cuts of the solved handle P, one per structural column cols[t] (1-based, basic): vals[t][0..n] with
-// vals[t][0] = rhs[t] = the cut's lower bound (gmi.cpp:91-109), ok[t] = 0 where no valid cut exists.
-// mode 0 = generateCut3 as written (gmi.cpp:11-117), 1 = the repaired formula (mvx_generateCutGMI).
-int engine_gmi_cuts(const mvx_prob *Pc, int mode, const int *cols, int count, double *vals, double *rhs, int *ok) {
-  mvx_prob *P = const_cast<mvx_prob *>(Pc);
-  if (!P->valid || count < 1) return -1;
+// `count` cuts, cut t taken from the solved handle Ps[t] for its structural column cols[t] (1-based, basic):
+// vals[t][0..n] with vals[t][0] = rhs[t] = the cut's lower bound (gmi.cpp:91-109), ok[t] = 0 where no valid cut exists.
+// mode 0 = generateCut3 as written (gmi.cpp:11-117), 1 = the repaired formula (mvx_generateCutGMI).  The handles share
+// their columns and their first m0 model rows (B&B nodes of one tree: the root's rows are the same objects in every
+// clone); each has its own tableau, basis and appended cut rows.  One launch pair for all of them: a round of a B&B
+// window takes one cut from each of its branching nodes (bs.cpp:249-258 with cut.cpp:20's "last cut only").
+static int gmi_core(mvx_prob *const *Ps, int mode, const int *cols, int count, double *vals, double *rhs, int *ok) {
+  if (count < 1) return -1;
   Context &c = ctx();
   MAIN_LOCK(c);
   flush_copies(c);
   SolveCtx &sc = c.main;
-  const int m = P->m, n = P->n;
-  if (!dev_matrix_current(P)) {
-    P->dmat = build_dev_matrix(c, P);
-    if (!P->dmat) return -2;
+  const int n = Ps[0]->n;
+  int mmax = 0;
+  for (int t = 0; t < count; t++) {
+    if (!Ps[t]->valid || Ps[t]->n != n) return -1;
+    mmax = std::max(mmax, Ps[t]->m);
   }
-  const DevMatrix &D = *P->dmat;
-  const size_t wld = align_up((size_t)m + n + 1, 32), old = align_up((size_t)n + 1, 32);
+  // one device copy of the shared model rows serves every handle whose first m0 rows are those objects
+  std::shared_ptr<DevMatrix> Dp;
+  for (int t = 0; t < count && !Dp; t++)
+    if (dev_matrix_current(Ps[t])) Dp = Ps[t]->dmat;
+  if (!Dp) {
+    Dp = build_dev_matrix(c, Ps[0]);
+    if (!Dp) return -2;
+    Ps[0]->dmat = Dp;
+  }
+  for (int t = 0; t < count; t++) {
+    mvx_prob *P = Ps[t];
+    if (P->dmat == Dp) continue;
+    P->dmat = Dp;
+    if (!dev_matrix_current(P)) { // not a clone of the same root: its own copy, and it cannot share this launch
+      P->dmat = nullptr;
+      return -3;
+    }
+  }
+  const DevMatrix &D = *Dp;
+  const size_t wld = align_up((size_t)mmax + n + 1, 32), old = align_up((size_t)n + 1, 32);
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     size_t o = off;
     off = align_up(off + bytes, 256);
     return o;
   };
-  // [pos i32 x count][kind i32 x (n+1)] go up; [rhs][ok][out][work] come back (work: the auxiliaries' part only)
-  const size_t o_pos = carve((size_t)count * 4), o_kind = carve((size_t)(n + 1) * 4), up_bytes = off;
+  // [node descriptors x count][kind i32 x (n+1)] go up; [rhs][ok][out][work] come back (work: the auxiliaries' part only)
+  const size_t o_nodes = carve((size_t)count * sizeof(GmiNode)), o_kind = carve((size_t)(n + 1) * 4), up_bytes = off;
   const size_t o_rhs = carve((size_t)count * 8), o_ok = carve((size_t)count * 4);
   const size_t o_out = carve((size_t)count * old * 8), o_work = carve((size_t)count * wld * 8);
   if (off > c.gmi_bytes) {
@@ -2039,33 +2087,40 @@ int engine_gmi_cuts(const mvx_prob *Pc, int mode, const int *cols, int count, do
     c.gmi_bytes = want;
   }
   unsigned char *hb = (unsigned char *)c.gmi_host, *db = (unsigned char *)c.gmi_dev;
-  int *h_pos = (int *)(hb + o_pos), *h_kind = (int *)(hb + o_kind);
+  GmiNode *h_nodes = (GmiNode *)(hb + o_nodes);
+  int *h_kind = (int *)(hb + o_kind);
+  bool own_rows = false;
   for (int t = 0; t < count; t++) {
+    const mvx_prob *P = Ps[t];
     const int j = cols[t];
-    if (j < 1 || j > n || P->pos[(size_t)m + j] <= 0) return -1; // the column must be basic (gmi.cpp:23)
-    h_pos[t] = P->pos[(size_t)m + j];
+    if (j < 1 || j > n || P->pos[(size_t)P->m + j] <= 0) return -1; // the column must be basic (gmi.cpp:23)
+    GmiNode &nd = h_nodes[t];
+    nd.T = P->d_T; nd.nvar = P->d_nvar; nd.nflag = P->d_nflag; nd.nlb = P->d_nlb; nd.nub = P->d_nub;
+    nd.m = P->m; nd.ld = P->ld; nd.pos = P->pos[(size_t)P->m + j]; nd.pad = 0;
+    own_rows = own_rows || P->m > D.m0;
   }
   h_kind[0] = 0;
-  for (int j = 1; j <= n; j++) h_kind[j] = P->kind[(size_t)j];
+  for (int j = 1; j <= n; j++) h_kind[j] = Ps[0]->kind[(size_t)j];
   HIPCHECK(hipMemcpyAsync(db, hb, up_bytes, hipMemcpyHostToDevice, sc.stream));
   GmiArgs a;
-  a.T = P->d_T; a.nvar = P->d_nvar; a.nflag = P->d_nflag; a.nlb = P->d_nlb; a.nub = P->d_nub;
-  a.kind = (const int *)(db + o_kind); a.pos = (const int *)(db + o_pos);
+  a.nodes = (const GmiNode *)(db + o_nodes);
+  a.kind = (const int *)(db + o_kind);
   a.work = (double *)(db + o_work); a.rhs = (double *)(db + o_rhs); a.ok = (int *)(db + o_ok);
   a.A = mode == 0 ? D.packed : D.plain; a.len = mode == 0 ? D.len : nullptr; a.out = (double *)(db + o_out);
-  a.ld = P->ld; a.m = m; a.n = n; a.wld = (int)wld; a.lda = D.lda; a.m0 = D.m0; a.old = (int)old; a.count = count; a.mode = mode;
+  a.n = n; a.wld = (int)wld; a.lda = D.lda; a.m0 = D.m0; a.old = (int)old; a.count = count; a.mode = mode;
   launch_gmi(a, sc.stream);
   HIPCHECK(hipMemcpyAsync(hb + o_rhs, db + o_rhs, o_work - o_rhs, hipMemcpyDeviceToHost, sc.stream)); // rhs, ok, out
-  if (m > D.m0) // the auxiliaries of the rows appended since: their terms are added below
-    HIPCHECK(hipMemcpy2DAsync(hb + o_work, wld * 8, db + o_work, wld * 8, (size_t)(m + 1) * 8, (size_t)count, hipMemcpyDeviceToHost, sc.stream));
+  if (own_rows) // the auxiliaries of the rows appended since: their terms are added below
+    HIPCHECK(hipMemcpy2DAsync(hb + o_work, wld * 8, db + o_work, wld * 8, (size_t)(mmax + 1) * 8, (size_t)count, hipMemcpyDeviceToHost, sc.stream));
   HIPCHECK(hipStreamSynchronize(sc.stream));
   const double *h_rhs = (const double *)(hb + o_rhs), *h_out = (const double *)(hb + o_out), *h_work = (const double *)(hb + o_work);
   const int *h_ok = (const int *)(hb + o_ok);
   for (int t = 0; t < count; t++) {
+    const mvx_prob *P = Ps[t];
     double *v = vals + (size_t)t * (n + 1);
     std::memcpy(v + 1, h_out + (size_t)t * old + 1, (size_t)n * 8);
     // rows m0+1..m (this node's own cut rows) in order, the way gmi.cpp:81-89 / the repaired loop continue
-    for (int i = D.m0 + 1; i <= m; i++) {
+    for (int i = D.m0 + 1; i <= P->m; i++) {
       const double wi = h_work[(size_t)t * wld + i];
       const double *ai = P->A[(size_t)i]->data();
       if (mode == 0) {
@@ -2086,6 +2141,16 @@ int engine_gmi_cuts(const mvx_prob *Pc, int mode, const int *cols, int count, do
     ok[t] = h_ok[t];
   }
   return 0;
+}
+
+int engine_gmi_cuts(const mvx_prob *Pc, int mode, const int *cols, int count, double *vals, double *rhs, int *ok) {
+  if (count < 1) return -1;
+  std::vector<mvx_prob *> Ps((size_t)count, const_cast<mvx_prob *>(Pc));
+  return gmi_core(Ps.data(), mode, cols, count, vals, rhs, ok);
+}
+
+int engine_gmi_cuts_many(const mvx_prob *const *Ps, int mode, const int *cols, int count, double *vals, double *rhs, int *ok) {
+  return gmi_core(const_cast<mvx_prob *const *>(Ps), mode, cols, count, vals, rhs, ok);
 }
 
 // ------------------------------------------------------------------ pack / unpack (migration)

@@ -31,6 +31,7 @@ int engine_get_row(const mvx_prob *P, int row, double *out); // out[0..n]
 
 // GMI cuts of a solved node on the device (gmi.cpp:11-117); see engine.cpp
 int engine_gmi_cuts(const mvx_prob *P, int mode, const int *cols, int count, double *vals, double *rhs, int *ok);
+int engine_gmi_cuts_many(const mvx_prob *const *Ps, int mode, const int *cols, int count, double *vals, double *rhs, int *ok);
 
 long long engine_pack_size(const mvx_prob *P, int m_base);
 int engine_pack(const mvx_prob *P, int m_base, void *dev_buf);

@@ -3511,8 +3511,9 @@ __global__ __launch_bounds__(256) void k_gmi_work(GmiArgs a) {
   __shared__ double s_rhs, s_temp;
   __shared__ int s_bad;
   const int c = (int)blockIdx.x;
-  const int m = a.m, n = a.n;
-  const double *row = a.T + (size_t)a.pos[c] * a.ld;
+  const GmiNode nd = a.nodes[c];
+  const int m = nd.m, n = a.n;
+  const double *row = nd.T + (size_t)nd.pos * nd.ld;
   double *work = a.work + (size_t)c * a.wld;
   for (int v = TIDX; v <= m + n; v += 256) work[v] = 0.0;
   const double beta = row[0];
@@ -3528,10 +3529,10 @@ __global__ __launch_bounds__(256) void k_gmi_work(GmiArgs a) {
     for (int t = TIDX; t < cnt; t += 256) {
       const int jj = base + t;
       const double val = row[jj];
-      const int var = a.nvar[jj];
+      const int var = nd.nvar[jj];
       // glp_get_col_kind: an integer column with bounds [0,1] reads as GLP_BV; auxiliaries are continuous
       int kind = MVX_CV;
-      const double lb = a.nlb[jj], ub = a.nub[jj];
+      const double lb = nd.nlb[jj], ub = nd.nub[jj];
       if (var > m) {
         kind = a.kind[var - m];
         if (kind == MVX_IV && lb == 0.0 && ub == 1.0) kind = MVX_BV;
@@ -3543,7 +3544,7 @@ __global__ __launch_bounds__(256) void k_gmi_work(GmiArgs a) {
         s_aux[t] = api_ub(ub); // gmi.cpp:47,52
       } else {
         // repaired: this column's term of the cut and of its right-hand side
-        const int stat = a.nflag[jj];
+        const int stat = nd.nflag[jj];
         int code = 0; // 0 skip, 1 at lower, 2 at upper
         double g = 0.0, term = 0.0;
         if (val != 0.0 && stat != MVX_NS) {
@@ -3617,7 +3618,7 @@ __global__ __launch_bounds__(256) void k_gmi_backsub(GmiArgs a) {
   const bool act = col <= a.n;
   double acc[GMI_CT];
 #pragma unroll
-  for (int u = 0; u < GMI_CT; u++) acc[u] = (act && c0 + u < a.count) ? a.work[(size_t)(c0 + u) * a.wld + a.m + col] : 0.0;
+  for (int u = 0; u < GMI_CT; u++) acc[u] = (act && c0 + u < a.count) ? a.work[(size_t)(c0 + u) * a.wld + a.nodes[c0 + u].m + col] : 0.0;
   for (int i0 = 1; i0 <= a.m0; i0 += 64) {
     __syncthreads();
     {

@@ -199,20 +199,26 @@ struct CopyBatch {
   CopyJob jobs[COPY_BATCH];
 };
 
-// arguments of the GMI cut kernels (k_gmi_work / k_gmi_backsub): `count` cuts of one solved handle
-struct GmiArgs {
-  const double *T;     // tableau
+// one cut of a GMI launch: the solved handle it is taken from (a round of a B&B window takes one cut from each of up to
+// 64 node LPs: same columns and same first m0 model rows, their own tableaux, bases and appended cut rows)
+struct GmiNode {
+  const double *T; // tableau
   const int *nvar, *nflag;
   const double *nlb, *nub;
+  int m, ld, pos, pad; // rows of this handle, its row stride, the tableau row of the cut's basic column
+};
+
+// arguments of the GMI cut kernels (k_gmi_work / k_gmi_backsub): `count` cuts, each with its node
+struct GmiArgs {
+  const GmiNode *nodes; // [count]
   const int *kind;     // [n+1] column kinds of the model (MVX_CV / MVX_IV), device copy
-  const int *pos;      // [count] tableau row of each cut's basic column
   double *work;        // [count][wld] coefficients by variable number 0..m+n (gmi.cpp:29-32 `work`)
   double *rhs;         // [count]
   int *ok;             // [count] 0 = no valid cut (repaired mode: free non-basic with a non-zero entry)
   const double *A;     // [m0+1][lda] model rows 1..m0: packed non-zeros (bug-compatible) or by column (repaired)
   const int *len;      // [m0+1] non-zeros per row (nullptr: every row dense)
   double *out;         // [count][old] cut coefficients by structural column 1..n after rows 1..m0
-  int ld, m, n, wld, lda, m0, old, count, mode; // mode 0 bug-compatible (gmi.cpp:41-89), 1 repaired
+  int n, wld, lda, m0, old, count, mode; // mode 0 bug-compatible (gmi.cpp:41-89), 1 repaired
 };
 
 // shared immutable matrix row (1-based, n+1 doubles)

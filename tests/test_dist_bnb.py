@@ -151,3 +151,40 @@ def test_world2_on_the_config5_instance(orc, tmp_path):
     assert_same(res[0], res[1])
     assert treedigest.digest(res[0]) == fx["prefix"]["200"]["sha256"]
     assert res[0]["total_pivots"] == fx["prefix"]["200"]["pivots"]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_world4_and_world8_match_serial_with_the_same_dealing_in_both_coordinators(orc, tmp_path, world):
+    """The farm at the widths the node has (4 and 8 ranks over gloo, oracle engine per rank): same tree, decisions and
+    incumbent as the serial driver; every rank ends with the same replicated result; the Python coordinator and the C++
+    entry deal the children identically (same migration counts); children mostly stay on their parent's rank."""
+    case = (16, 32, 5, 2)
+    A, b, c, U = synth.dense_ilp(*case)
+    serial = canon(bnb.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=0, table=bnb.table_from(orc)))
+    kw = dict(quirks=0, per_rank=8)
+    py = dist_helpers.run_world(world, case, kw, str(tmp_path))
+    nat = dist_helpers.run_world_native(world, case, kw, str(tmp_path))
+    for res in (py, nat):
+        for r in range(1, world):
+            assert_same(res[0], res[r])
+        assert_same(res[0], serial)
+    sp, sn = py[0]["dist"], nat[0]["dist"]
+    assert sp["children"] == sn["children"] > 4000
+    assert sp["migrated"] == sn["migrated"] and sp["rounds"] == sn["rounds"]
+    assert 0 < sp["migrated"] < 0.35 * sp["children"], sp  # round-robin dealing would move (world - 1) / world of them
+
+
+def test_world4_on_the_config5_instance(orc, tmp_path):
+    """BASELINE config 5 on four ranks: the first 200 nodes of the calibrated 512x1024 tree equal the oracle's serial
+    record in tests/golden/config5.json (C++ entry over gloo)."""
+    import os
+
+    from mvolps_amd import treedigest
+
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5.json")))
+    case = (fx["m"], fx["n"], fx["seed"], fx["U"], fx["cap"])
+    res = dist_helpers.run_world_native(4, case, dict(quirks=0, max_nodes=200, per_rank=4), str(tmp_path))
+    for r in range(1, 4):
+        assert_same(res[0], res[r])
+    assert treedigest.digest(res[0]) == fx["prefix"]["200"]["sha256"]
+    assert res[0]["total_pivots"] == fx["prefix"]["200"]["pivots"]

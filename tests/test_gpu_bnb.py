@@ -219,6 +219,32 @@ def test_config5_full_tree_equals_the_oracle_record(gpu):
     _matches(r, rec)
     assert float(r["best_lower"]).hex() == rec["best_lower"] and r["incumbent_oid"] == rec["incumbent_oid"]
     assert [(j + 1, v) for j, v in enumerate(r["x"]) if v != 0.0] == [tuple(t) for t in rec["x_nonzero"]]
+    # ... and the optimum is the one an independent solver finds (HiGHS milp, tests/golden/milp_pins.json)
+    pin = _milp_pins()["config5"]["milp_obj"]
+    assert abs(r["best_lower"] - pin) <= 1e-9 * abs(pin)
+
+
+def _milp_pins():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "milp_pins.json")))
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_cut_path_closes_on_the_milp_optimum(gpu, orc, which):
+    """Config-3 path end to end against an independent solver: a 128x256 ILP whose FIFO tree closes WITH repaired GMI cuts
+    (about 10 000 nodes); the optimum equals the HiGHS milp optimum, tree and pivot counts equal the oracle's."""
+    from oracle import oracle
+
+    pin = _milp_pins()["cut_ilps"][which]
+    A, b, c, U = synth.dense_ilp(pin["m"], pin["n"], pin["seed"], pin["U"], pin["cap"])
+    kw = dict(quirks=0, cut_strat=1)
+    got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), **kw)
+    assert not got["hit_limit"] and got["count"] > 5000
+    assert abs(got["best_lower"] - pin["milp_obj"]) <= 1e-9 * abs(pin["milp_obj"])
+    ref = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), **kw)
+    same_result(got, ref)
 
 
 @pytest.mark.parametrize("window", [1, 32])

@@ -152,3 +152,21 @@ def test_config5_fixture_is_the_oracles_record(orc):
     r = oracle.branch_and_bound(synth.load_ilp(orc, A, b, c, U), quirks=0, max_nodes=200)
     rec = fx["prefix"]["200"]
     assert treedigest.digest(r) == rec["sha256"] and r["total_pivots"] == rec["pivots"]
+
+
+def test_config5_and_cut_path_optima_equal_highs_milp(orc):
+    """Independent pins for whole B&B runs (tests/golden/milp_pins.json, HiGHS milp): the optimum recorded for the
+    calibrated config-5 tree, and a 128x256 ILP closed by the oracle WITH repaired GMI cuts (config-3 path)."""
+    from oracle import oracle
+
+    here = os.path.dirname(__file__)
+    pins = json.load(open(os.path.join(here, "golden", "milp_pins.json")))
+    fx = json.load(open(os.path.join(here, "golden", "config5.json")))
+    assert (fx["m"], fx["n"], fx["seed"], fx["U"], fx["cap"]) == tuple(pins["config5"][k] for k in ("m", "n", "seed", "U", "cap"))
+    best = float.fromhex(fx["full"]["best_lower"])
+    assert abs(best - pins["config5"]["milp_obj"]) <= 1e-9 * abs(best)
+    pin = pins["cut_ilps"][0]
+    A, b, c, U = synth.dense_ilp(pin["m"], pin["n"], pin["seed"], pin["U"], pin["cap"])
+    r = oracle.branch_and_bound(lpgen.load_ilp(orc, A, b, c, U), quirks=0, cut_strat=1)
+    assert not r["hit_limit"] and r["count"] > 5000
+    assert abs(r["best_lower"] - pin["milp_obj"]) <= 1e-9 * abs(pin["milp_obj"])
