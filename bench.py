@@ -219,6 +219,24 @@ def secondary(api, with_cpu=True):
                                                   "same_tree": treedigest.digest(r3) == treedigest.digest(r), "per_rank": 64}
     if with_cpu:
         out["bnb_ilp_512x1024"]["cpu_baseline"] = bnb_cpu_baseline((A, b, c, U), 0)
+    # config 3: the same ILP with GMI cuts (gmi.cpp / cut.cpp path): bug-compatible (bs.cpp as written: the pool's last cut
+    # at every branching node) and repaired; one cut per branching node, made for the whole window in one device pass
+    cuts = {}
+    for name, kw in (("bug_compatible", dict(quirks=1, cut_strat=1)), ("repaired", dict(quirks=0, cut_strat=1))):
+        bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), max_nodes=64, **kw)  # warm-up
+        t0 = time.perf_counter()
+        rc = bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), max_nodes=600, **kw)
+        el = time.perf_counter() - t0
+        cuts[name] = {"nodes": rc["count"], "nodes_per_s": rc["count"] / el, "pivots": rc["total_pivots"], "window": 64}
+    out["bnb_ilp_512x1024_cuts"] = {"driver": "mvx_branchAndBound", "instance": "wide (cap 0.4, U 3), first 600 nodes, one GMI cut per branching node", **cuts}
+    if with_cpu:
+        from oracle import oracle
+
+        t0 = time.perf_counter()
+        ro = oracle.branch_and_bound(synth.load_ilp(oracle.api(), A, b, c, U), quirks=1, cut_strat=1, max_nodes=40)
+        el = time.perf_counter() - t0
+        out["bnb_ilp_512x1024_cuts"]["cpu_baseline"] = {"value": ro["count"] / el, "unit": "nodes/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                                                        "sample": "first %d nodes of the bug-compatible tree, oracle/mvolps_oracle_bnb.c" % ro["count"]}
     fx, inst = config5_instance()
     if fx.get("full"):
         A5, b5, c5, U5 = inst

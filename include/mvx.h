@@ -115,6 +115,8 @@ int mvx_get_status(const mvx_prob *P);                /* util.cpp:423 */
 double mvx_get_obj_val(const mvx_prob *P);            /* bs.cpp:125,156,190,210,280,288 */
 double mvx_get_obj_coef(const mvx_prob *P, int j);    /* bs.cpp:182,190; util.cpp:437,455 */
 double mvx_get_col_prim(const mvx_prob *P, int j);    /* bs.cpp:182,232,261; gmi.cpp:37 */
+/* extension: glp_get_col_prim for every column in one call, x[1..n] (util.cpp:414-473 reads them all for every node) */
+void mvx_get_col_prim_all(const mvx_prob *P, double *x);
 double mvx_get_row_prim(const mvx_prob *P, int i);
 double mvx_get_col_dual(const mvx_prob *P, int j);
 double mvx_get_row_dual(const mvx_prob *P, int i);

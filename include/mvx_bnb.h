@@ -64,6 +64,9 @@ typedef struct mvx_lp_api {
   /* optional (may be NULL): one cut from each of `count` different solved handles (mvx_gmi_cuts_many): the window driver
      generates the cuts of a whole round through it */
   int (*gmi_cuts_many)(const void *const *Ps, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok);
+  /* optional (may be NULL): get_col_prim for every column at once, x[1..n] -- printInfo (util.cpp:414-473) reads all n
+     values of every node */
+  void (*get_col_prim_all)(const void *P, double *x);
 } mvx_lp_api;
 
 const mvx_lp_api *mvx_hip_lp_api(void);

@@ -14,7 +14,7 @@ _FIELDS = [
     "get_col_stat", "get_row_stat", "get_row_ub", "get_row_lb", "get_col_ub", "get_col_lb", "get_col_type", "get_mat_row", "eval_tab_row",
     "get_it_cnt",
 ]
-_OPTIONAL = ["simplex_batch", "get_obj_dir", "gmi_cuts", "gmi_cuts_many"]
+_OPTIONAL = ["simplex_batch", "get_obj_dir", "gmi_cuts", "gmi_cuts_many", "get_col_prim_all"]
 
 
 class LpApiTable(C.Structure):

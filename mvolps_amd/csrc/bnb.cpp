@@ -69,14 +69,24 @@ std::pair<int, std::vector<int>> printInfo(const mvx_lp_api *api, const void *pr
   std::vector<int> violated;
   const int status = api->get_status(prob);
   if (status == MVX_NOFEAS || status == MVX_INFEAS || status == MVX_UNBND) return {-1, violated}; // util.cpp:424
+  std::vector<double> xs;
+  if (api->get_col_prim_all) { // one call instead of n through the table
+    xs.resize((size_t)cols + 1);
+    api->get_col_prim_all(prob, xs.data());
+  }
+  // this loop runs over every column of every node: trunc / round without a libm call per column (values beyond 2^52
+  // are integers; |v - round(v)| = min(|f|, 1 - |f|) with f = v - trunc(v), exact wherever it is near the tolerance)
+  auto trunc_of = [](double v) { return std::fabs(v) < 4503599627370496.0 ? (double)(long long)v : v; };
   for (int i = 1; i <= cols; i++) {
-    const double v = api->get_col_prim(prob, i);
+    const double v = xs.empty() ? api->get_col_prim(prob, i) : xs[(size_t)i];
+    const double t = trunc_of(v);
     if (!quirks) {
-      if (std::fabs(v - std::round(v)) > 1e-9 && api->get_col_kind(prob, i) != MVX_CV) violated.push_back(i);
+      const double f = std::fabs(v - t);
+      if ((f < 1.0 - f ? f : 1.0 - f) > 1e-9 && api->get_col_kind(prob, i) != MVX_CV) violated.push_back(i);
       continue;
     }
-    if (v != 0 && api->get_obj_coef(prob, i) != 0) {                      // util.cpp:437
-      if (std::trunc(v) != v && api->get_col_kind(prob, i) != MVX_CV) {   // util.cpp:443-444
+    if (v != 0 && api->get_obj_coef(prob, i) != 0) {            // util.cpp:437
+      if (t != v && api->get_col_kind(prob, i) != MVX_CV) {     // util.cpp:443-444
         violated.push_back(i);
       }
     }
@@ -463,7 +473,11 @@ static std::vector<std::unique_ptr<CutContainer>> round_cuts(const mvx_lp_api *a
   const int n = api->get_num_cols(ps[0]);
   std::vector<double> vals((size_t)k * (n + 1)), rhs((size_t)k);
   std::vector<int> ok((size_t)k, 0);
-  if (api->gmi_cuts_many(ps.data(), quirks ? 0 : 1, cols.data(), k, vals.data(), rhs.data(), ok.data()) != 0) return out;
+  const int grc = api->gmi_cuts_many(ps.data(), quirks ? 0 : 1, cols.data(), k, vals.data(), rhs.data(), ok.data());
+  if (grc != 0) {
+    if (std::getenv("MVX_BNB_TIMING")) std::fprintf(stderr, "round_cuts: gmi_cuts_many returned %d for %d cuts\n", grc, k);
+    return out;
+  }
   for (int t = 0; t < k; t++) {
     if (!ok[(size_t)t]) continue;
     const double *v = &vals[(size_t)t * (n + 1)];
@@ -772,7 +786,7 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
   if (const char *e = std::getenv("MVX_BNB_DEPTH")) depth = (size_t)std::max(1, std::min(4, std::atoi(e)));
   CutPool pool(api); // persistent across nodes in bug-compatible mode (cut.h:15-23)
   const bool timing = std::getenv("MVX_BNB_TIMING") != nullptr;
-  double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tB_cuts = 0, tWait = 0;
+  double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tB_cuts = 0, tB_rcuts = 0, tWait = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
   // wait for a round's children, book their results, flush the round's events
@@ -844,18 +858,29 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     // printInfo of the window is taken ahead for that and reused by the replay
     std::vector<std::pair<int, std::vector<int>>> info;
     std::vector<std::unique_ptr<CutContainer>> pre;
-    if (prm.cut_strat != 0 && prm.lazy_pool && api->gmi_cuts_many && W > 1) {
+    if (W >= 8) {
+      // printInfo (util.cpp:414-473) of the whole window ahead of the replay, on a few threads: it reads every column
+      // value of a node out of host mirrors that no cache holds yet (a window's nodes were solved rounds ago), ~15 us a
+      // node when done one after the other inside the replay; the nodes are independent, the replay reuses the results
       info.resize(W);
-      std::vector<char> wanted(W, 0);
       double ti = now();
-      for (size_t w = 0; w < W; w++) {
-        info[w] = printInfo(api, a[w], quirks);
-        wanted[w] = info[w].first == 0; // neither infeasible nor integral: branches unless its bound prunes it
-      }
+      const size_t parts = std::min<size_t>(4, W / 4);
+      std::vector<std::future<void>> fs;
+      for (size_t part = 1; part < parts; part++)
+        fs.push_back(std::async(std::launch::async, [&, part]() {
+          for (size_t w = part * W / parts; w < (part + 1) * W / parts; w++) info[w] = printInfo(api, a[w], quirks);
+        }));
+      for (size_t w = 0; w < W / parts; w++) info[w] = printInfo(api, a[w], quirks);
+      for (auto &f : fs) f.get();
       tB_info += now() - ti;
-      ti = now();
+    }
+    if (prm.cut_strat != 0 && prm.lazy_pool && api->gmi_cuts_many && !info.empty()) {
+      std::vector<char> wanted(W, 0);
+      for (size_t w = 0; w < W; w++) wanted[w] = info[w].first == 0; // neither infeasible nor integral: branches unless its bound prunes it
+      const double ti = now();
       pre = round_cuts(api, a, wanted, prm, quirks);
       tB_cuts += now() - ti;
+      tB_rcuts += now() - ti;
     }
     // B. replay in queue order
     Round cur;
@@ -1029,8 +1054,8 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
   }
   while (!flight.empty()) finalize_oldest();
   if (timing)
-    std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f, cuts %.1f)  waiting for child solves %.1f ms\n", tA * 1e3,
-                 tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tB_cuts * 1e3, tWait * 1e3);
+    std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f, cuts %.1f of which the round's device pass %.1f)  waiting for child solves %.1f ms\n", tA * 1e3,
+                 tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tB_cuts * 1e3, tB_rcuts * 1e3, tWait * 1e3);
   leafContainer.clear();
   pack_result(res, rec, id, count, has_incumbent, bestLower, incumbent_oid, n0, xbest, hit_limit);
   return 0;
@@ -1074,6 +1099,7 @@ const mvx_lp_api g_hip_api = {
     [](const void *const *Ps, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
       return mvx_gmi_cuts_many((const mvx_prob *const *)Ps, repaired, cols, count, vals, rhs, ok);
     },
+    [](const void *P, double *x) { mvx_get_col_prim_all((const mvx_prob *)P, x); },
 };
 
 } // namespace

@@ -316,6 +316,9 @@ double mvx_get_col_prim(const mvx_prob *P, int j) {
   if (j < 1 || j > P->n) fault("get_col_prim: column out of range");
   return var_prim(P, P->m + j);
 }
+void mvx_get_col_prim_all(const mvx_prob *P, double *x) { // x[1..n], x[0] untouched: glp_get_col_prim for every column at once
+  for (int j = 1; j <= P->n; j++) x[j] = var_prim(P, P->m + j);
+}
 double mvx_get_row_prim(const mvx_prob *P, int i) {
   if (i < 1 || i > P->m) fault("get_row_prim: row out of range");
   return var_prim(P, i);

@@ -1964,10 +1964,10 @@ int engine_get_row(const mvx_prob *P, int row, double *out) {
 }
 
 // ------------------------------------------------------------------------ GMI cuts (gmi.cpp:11-117)
-static std::shared_ptr<DevMatrix> build_dev_matrix(Context &c, const mvx_prob *P) {
+static std::shared_ptr<DevMatrix> build_dev_matrix(Context &c, const mvx_prob *P, int rows = -1) { // rows: only the first `rows` (default: all)
   SolveCtx &sc = c.main;
   auto D = std::make_shared<DevMatrix>();
-  const int m0 = P->m, n = P->n;
+  const int m0 = (rows >= 0 && rows < P->m) ? rows : P->m, n = P->n;
   const int lda = (int)align_up((size_t)n + 1, LD_ALIGN);
   D->m0 = m0;
   D->n = n;
@@ -2041,24 +2041,28 @@ static int gmi_core(mvx_prob *const *Ps, int mode, const int *cols, int count, d
     if (!Ps[t]->valid || Ps[t]->n != n) return -1;
     mmax = std::max(mmax, Ps[t]->m);
   }
-  // one device copy of the shared model rows serves every handle whose first m0 rows are those objects
+  // One device copy of the model rows the handles have in common serves them all: the rows every handle shares, object
+  // for object, from row 1 on (the root's rows, and the cut rows of the ancestors the whole window descends from); what
+  // a handle has beyond that -- its own lineage's cut rows -- is added on the host below, as for rows appended later.
+  int common = Ps[0]->m;
+  for (int t = 1; t < count; t++) {
+    const mvx_prob *P = Ps[t];
+    common = std::min(common, P->m);
+    int i = 1;
+    while (i <= common && P->A[(size_t)i].get() == Ps[0]->A[(size_t)i].get()) i++;
+    common = i - 1;
+  }
+  if (common < 1) return -3; // not clones of one root
   std::shared_ptr<DevMatrix> Dp;
-  for (int t = 0; t < count && !Dp; t++)
-    if (dev_matrix_current(Ps[t])) Dp = Ps[t]->dmat;
+  for (int t = 0; t < count; t++) { // the deepest copy at hand that covers no more than the common rows
+    const mvx_prob *P = Ps[t];
+    if (P->dmat && P->dmat->m0 <= common && dev_matrix_current(P) && (!Dp || P->dmat->m0 > Dp->m0)) Dp = P->dmat;
+  }
   if (!Dp) {
-    Dp = build_dev_matrix(c, Ps[0]);
+    Dp = build_dev_matrix(c, Ps[0], common);
     if (!Dp) return -2;
-    Ps[0]->dmat = Dp;
   }
-  for (int t = 0; t < count; t++) {
-    mvx_prob *P = Ps[t];
-    if (P->dmat == Dp) continue;
-    P->dmat = Dp;
-    if (!dev_matrix_current(P)) { // not a clone of the same root: its own copy, and it cannot share this launch
-      P->dmat = nullptr;
-      return -3;
-    }
-  }
+  for (int t = 0; t < count; t++) Ps[t]->dmat = Dp; // (their children inherit it)
   const DevMatrix &D = *Dp;
   const size_t wld = align_up((size_t)mmax + n + 1, 32), old = align_up((size_t)n + 1, 32);
   size_t off = 0;
