@@ -714,201 +714,9 @@ __device__ int dual_chain(const KC &k, Ctl *c, Cand *lds, int kmax) {
   return nch;
 }
 
-// The same chain with the workgroup's state kept on chip (node LPs of up to 1024 rows and 1024 columns: one row and one
-// column per thread).  dual_chain re-derives everything from memory at every step -- column 0, the bounds, the objective
-// row, the statuses carried through the chain with a global load per earlier step -- five dependent stages of memory
-// round trips, 11.5 us per step; the calibrated config-5 tree spends 77 % of its GPU time there (k_select, median
-// 46 us for four steps; profiles/r03_config5_kernel_stats.txt).  Here what a step changes lives in registers -- basic
-// values, bounds and dual devex weights of the rows; reduced costs and statuses of the columns; every thread's own
-// entries of the chain's pivot columns and scaled pivot rows -- so a step is two memory round trips (row p, column q)
-// and a handful of LDS exchanges.  Same arithmetic in the same order per entry; the result is bit for bit dual_chain's.
-struct DcSlot {
-  Cand c;
-  double pay[4];
-};
-template <int MODE>
-__device__ __forceinline__ Cand block_argbest16(Cand mine, const double (&pin)[4], double (&pout)[4], DcSlot *slots) {
-  const int lane = TIDX & 63, wave = TIDX >> 6;
-  int ol;
-  const Cand wb = wave_argbest<MODE>(mine, &ol);
-  double pv[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) pv[k] = rl_d(pin[k], ol);
-  if (lane == 0) {
-    slots[wave].c = wb;
-#pragma unroll
-    for (int k = 0; k < 4; k++) slots[wave].pay[k] = pv[k];
-  }
-  __syncthreads();
-  Cand rc{0.0, 0.0, 0, 0};
-  if (lane < 16) rc = slots[lane].c;
-  int wl;
-  const Cand win = wave_argbest<MODE>(rc, &wl);
-#pragma unroll
-  for (int k = 0; k < 4; k++) pout[k] = slots[wl].pay[k];
-  __syncthreads(); // the slots are reused by the next reduction
-  return win;
-}
-
-constexpr size_t DC_FAST_LDS = (size_t)2 * DCH_MAX * 1024 * 8; // the chain's history: one slot per thread, step and side
-__device__ __attribute__((noinline)) int dual_chain_fast(const KC &k, Ctl *c, int kmax) {
-  extern __shared__ double dc_hist[]; // [2][DCH_MAX][1024]: this thread's row of the chain's pivot columns / column of its scaled rows
-  __shared__ DcSlot s_slots[16];
-  __shared__ double s_hp[DCH_MAX], s_hq[DCH_MAX], s_misc[4];
-  __shared__ ChainStep sts[DCH_MAX]; // the chain so far (every thread holds the same values; thread 0 writes them down)
-  const int m = k.m, n = k.n, t = TIDX;
-  const size_t ld = (size_t)k.ld;
-  const double *const T = k.T;
-  const int budget = c->budget, stall_limit = c->stall_limit;
-  // ---- step 0 as select_step left it, and the state as of after it
-  const int p0 = c->p, q0 = c->q, lf0 = c->leave_flag;
-  const double piv0 = c->piv, xq0 = c->xq, s00 = k.srow[0];
-  const ChainStep st0{p0, q0, lf0, piv0, xq0, s00};
-  const int i = 1 + t, j = 1 + t;
-  const bool ract = (i <= m), cact = (j <= n);
-  const int ic = ract ? i : m, jc = cact ? j : n;
-#define DC_HC(L) dc_hist[(size_t)(L) * 1024 + t]
-#define DC_HS(L) dc_hist[(size_t)(DCH_MAX + (L)) * 1024 + t]
-  const double hc0 = k.colq[ic], hs0 = k.srow[jc];
-  DC_HC(0) = hc0;
-  DC_HS(0) = hs0;
-  const double dq0 = k.colq[0];
-  double be = chain_apply(st0, ic, 0, T[(size_t)ic * ld], hc0, s00);
-  double lb = (ic == p0) ? k.nlb[q0] : k.blb[ic], ub = (ic == p0) ? k.nub[q0] : k.bub[ic];
-  double dw = k.dw[ic];
-  double d = chain_apply(st0, 0, jc, T[jc], dq0, hs0);
-  int f = cact ? ((jc == q0) ? lf0 : k.nflag[jc]) : MVX_NS;
-  // bounds of the columns as the chain leaves them: column q takes the leaving variable's (needed for x_q of a later step)
-  double nlbj = (jc == q0) ? k.blb[p0] : k.nlb[jc], nubj = (jc == q0) ? k.bub[p0] : k.nub[jc];
-  int stall = c->stall;
-  int nch = 1;
-  if (t == 0) sts[0] = st0; // read behind the barriers of the first reduction
-  for (int kk = 1; kk < kmax; kk++) {
-    if ((budget >= 0 && budget < kk + 1) || stall >= stall_limit) break;
-    // ---- leaving row (dev_infeas_row on the carried values)
-    Cand rb{0.0, 0.0, 0, 0};
-    const double tolb = k.tol_bnd;
-    if (ract) {
-      double viol = 0.0;
-      int up = 0;
-      if (lb > -INFINITY && be < lb - tolb * (1.0 + fabs(lb))) viol = lb - be;
-      if (ub < INFINITY && be > ub + tolb * (1.0 + fabs(ub))) {
-        viol = be - ub;
-        up = 1;
-      }
-      if (viol > 0.0) rb = Cand{xdiv(viol * viol, dw), 0.0, i, up};
-    }
-    double rp[4] = {be, lb, ub, dw}, ro[4];
-    const Cand rw = block_argbest16<0>(rb, rp, ro, s_slots);
-    if (rw.idx == 0) break; // primal feasible: the next k_select changes phase
-    const int p = rw.idx, p_up = rw.aux;
-    const double bp = ro[0], plb = ro[1], pub = ro[2], wp = ro[3];
-    // ---- row p as of step kk: its entries of the earlier pivot columns come from the thread that owns the row
-    double a = T[(size_t)p * ld + jc];
-    if (i == p)
-      for (int l = 0; l < kk; l++) s_hp[l] = DC_HC(l);
-    __syncthreads();
-    for (int l = 0; l < kk; l++) a = chain_apply(sts[l], p, jc, a, s_hp[l], DC_HS(l));
-    // dual ratio test (dev_dual_ratio on the carried values)
-    Cand best{0.0, 0.0, 0, 0};
-    const double tp = k.tol_piv, sgn = k.sgn;
-    if (cact && f != MVX_NS) {
-      const double aa = p_up ? -a : a;
-      const double dd = sgn * d;
-      double r = 0.0;
-      bool ok = false;
-      if (aa > tp && (f == MVX_NL || f == MVX_NF)) {
-        r = (f == MVX_NF) ? fabs(dd) : (dd < 0.0 ? -dd : 0.0);
-        ok = true;
-      } else if (aa < -tp && (f == MVX_NU || f == MVX_NF)) {
-        r = (f == MVX_NF) ? fabs(dd) : (dd > 0.0 ? dd : 0.0);
-        ok = true;
-      }
-      if (ok) {
-        const double mag = fabs(a);
-        best = Cand{xdiv(r, mag), mag, j, 0};
-      }
-    }
-    double qp[4] = {a, d, nlbj, nubj}, qo[4];
-    const Cand qw = block_argbest16<1>(best, qp, qo, s_slots);
-    if (qw.idx == 0) break; // no entering column: the generic step reports it
-    const int q = qw.idx;
-    const double apq = qo[0], dq = qo[1], lbq = qo[2], ubq = qo[3];
-    // ---- column q as of step kk: its entries of the earlier scaled rows (and its status) come from its owner
-    double cq = T[(size_t)ic * ld + q];
-    if (j == q) {
-      for (int l = 0; l < kk; l++) s_hq[l] = DC_HS(l);
-      s_misc[0] = (double)f;
-    }
-    __syncthreads();
-    const int fq = (int)s_misc[0];
-    for (int l = 0; l < kk; l++) cq = chain_apply(sts[l], ic, q, cq, DC_HC(l), s_hq[l]);
-    const double bound = p_up ? pub : plb;
-    const int lf = dev_leave_flag(plb, pub, p_up);
-    const double s0 = xdiv(bp - bound, apq);
-    const double xq = dev_nb_value(fq, lbq, ubq);
-    const ChainStep stk{p, q, lf, apq, xq, s0};
-    double *const ck = c->colqk[kk], *const sk = c->srowk[kk];
-    // the rows: pivot column out, dual devex weights (select_step's pass), basic values and bounds after the step
-    if (ract) {
-      ck[i] = cq;
-      if (i == p) {
-        const double cc = xdiv(wp, apq * apq);
-        dw = cc > 1.0 ? cc : 1.0;
-      } else {
-        const double r = xdiv(cq, apq);
-        const double cc = r * r * wp;
-        if (cc > dw) dw = cc;
-      }
-      be = chain_apply(stk, i, 0, be, cq, s0);
-      if (i == p) {
-        lb = lbq;
-        ub = ubq;
-      }
-    }
-    DC_HC(kk) = cq;
-    // the columns: scaled pivot row out, reduced costs and statuses after the step
-    const double sj = xdiv(a, apq);
-    if (cact) sk[j] = sj;
-    d = chain_apply(stk, 0, jc, d, dq, sj);
-    if (cact && j == q) {
-      f = lf;
-      nlbj = plb;
-      nubj = pub;
-    }
-    DC_HS(kk) = sj;
-    stall = (qw.k1 <= DEGEN_TOL) ? stall + 1 : 0;
-    if (t == 0) {
-      sts[kk] = stk;
-      ck[0] = dq;
-      sk[0] = s0;
-      c->ch_p[kk] = p;
-      c->ch_q[kk] = q;
-      c->ch_lf[kk] = lf;
-      c->ch_piv[kk] = apq;
-      c->ch_xq[kk] = xq;
-      c->ch_s0[kk] = s0;
-    }
-    nch = kk + 1;
-  }
-#undef DC_HC
-#undef DC_HS
-  if (ract) k.dw[i] = dw; // the weights as the chain leaves them, where the next step reads them
-  if (t == 0) {
-    c->ch_p[0] = p0;
-    c->ch_q[0] = q0;
-    c->ch_lf[0] = lf0;
-    c->ch_piv[0] = piv0;
-    c->ch_xq[0] = xq0;
-    c->ch_s0[0] = s00;
-    c->stall = stall;
-  }
-  return nch;
-}
-
 // ---------------------------------------------------------------------------- k_select
 // Device-side restatement of orc_simplex's round loop + one pricing / ratio-test step.
-__device__ void select_step(Ctl *c, Cand *lds, int fast_lds = 0) {
+__device__ void select_step(Ctl *c, Cand *lds) {
   const KC k = load_kc(c); // every pointer / constant the step needs, fetched in one burst
   if (c->done != D_RUN) return;
   if (c->pc_itlim) { // k_chain saw the pivot limit fall on the end of its chain, with an entering column still on offer
@@ -1063,9 +871,7 @@ __device__ void select_step(Ctl *c, Cand *lds, int fast_lds = 0) {
     }
     if (c->dchain_max > 1 && !fresh_dual && !k.bland && phase == PH_DUAL) {
       __syncthreads(); // step 0 is complete: srow, colq, weights, the control block's pivot description
-      // node LPs of up to 1024 rows and columns (every B&B child at the BASELINE sizes): the register-resident chain
-      if (fast_lds && k.m <= 1024 && k.n <= 1024 && (int)blockDim.x == 1024) nch = dual_chain_fast(k, c, c->dchain_max);
-      else nch = dual_chain(k, c, lds, c->dchain_max);
+      nch = dual_chain(k, c, lds, c->dchain_max);
     }
   }
   if (TIDX == 0) {
@@ -1097,7 +903,7 @@ __device__ void pack_mirrors(const Ctl *c, unsigned char *stage, int t0, int ste
   }
 }
 
-__global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q, int fast_lds) {
+__global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
   __shared__ Cand lds[17];
   __shared__ int s_job;
   c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
@@ -1142,7 +948,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q, int fast_
     }
     __syncthreads();
   }
-  select_step(c, lds, fast_lds);
+  select_step(c, lds);
 }
 
 // ------------------------------------------------------------------------ phase-1 kernels
@@ -3985,29 +3791,12 @@ void launch_db(Ctl *d_ctl, int m, int n, hipStream_t s) {
 #undef DB_CASE
   std::abort(); // unreachable
 }
-// k_select with the LDS the register-resident dual chain keeps its history in (128 KB: one workgroup per CU, which a
-// 1024-thread workgroup nearly is anyway); without it (attribute refused) the chain re-derives its state from memory
-static size_t select_lds() {
-  static int state = -1; // -1 not tried, 0 refused, 1 granted
-  if (state < 0) {
-    const char *e = std::getenv("MVX_DCHAIN_FAST");
-    if (e && e[0] == '0') state = 0;
-    else if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DC_FAST_LDS) == hipSuccess) state = 1;
-    else {
-      (void)hipGetLastError();
-      state = 0;
-    }
-  }
-  return state == 1 ? DC_FAST_LDS : 0;
-}
 void launch_select(Ctl *d_ctl, hipStream_t s, int slots) {
   BatchQueue q{};
-  const size_t lds = select_lds();
-  hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), lds, s, d_ctl, q, lds ? 1 : 0);
+  hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl, q);
 }
 void launch_select_queue(Ctl *d_ctl, const BatchQueue &q, hipStream_t s, int slots) {
-  const size_t lds = select_lds();
-  hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), lds, s, d_ctl, q, lds ? 1 : 0);
+  hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl, q);
 }
 void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots, int chained) {
   const int pairs = (n + 2) / 2;
