@@ -936,6 +936,7 @@ struct SolveJob {
   bool persist_queued = false; // this batch of launches contains a k_persist launch (its abort flag is copied back)
   int seen_steps = 0, seen_pivots = 0, seen_bulk = 0;
   int chain = 1, chain0 = 1; // pivots per bulk launch the next batch is queued for / the size rule's choice
+  bool resident = false;     // this solve holds the token that lets it launch kernels whose workgroups must be resident together
   bool cluster = false;      // the chains of this solve are chosen by k_chain (one launch) instead of k_pc / k_pr per step
   ChainArgs cargs{};         // what the kernels of the chained primal path take by value
   size_t ev_used = 0;
@@ -1009,8 +1010,9 @@ static void job_begin(Context &c, SolveJob &J) {
   }
   // k_chain and k_persist need their workgroups resident together: two such launches from two host threads (the main
   // context and a B&B worker's) could each hold half of the CUs they both need and wait for the rest until they time
-  // out.  Only the main context, whose calls are serialised, uses them; the others take the plain kernels.
-  J.cluster = (J.sc == &c.main) && cluster_wanted() && chain_cluster_kmax(P->m, P->n) > 0;
+  // out.  One solve at a time may use them (solve_once holds the token for the length of the call); a solve that finds
+  // the token taken runs on the plain kernels.
+  J.cluster = J.resident && cluster_wanted() && chain_cluster_kmax(P->m, P->n) > 0;
   J.try_fused = !P->hint_dual; // dual-phase warm starts (B&B children) skip the primal fast path
   J.chain = J.chain0 = h->chain_max;
   J.try_dfused = P->hint_dual && dual_fused_worth_it(P);
@@ -1065,7 +1067,10 @@ static void job_enqueue(Context &c, SolveJob &J) {
   auto body = [&](int m_grid) {
     if (J.try_fused) {
       PersistPlan pl;
-      if (depth > 0 && !J.profiled && J.sc == &c.main && persist_plan(c, P, &pl) && ensure_persist(c, sc, P, pl)) {
+      // the resident-tableau kernel serves where the cluster chain is not on offer (mvx_set_cluster(0), a cluster launch
+      // that gave up): since round 3 the chain is the faster one at every size that fits k_persist (scripts/smalltime.py:
+      // 512x1024 9.1 against 12.3 us per pivot, 128x256 9.7 against 10.8)
+      if (depth > 0 && !J.profiled && J.resident && !(J.cluster && !g_cluster_broken.load()) && persist_plan(c, P, &pl) && ensure_persist(c, sc, P, pl)) {
         // cache-resident size: one generic step settles the phase, then the whole run of primal pivots in ONE launch
         // with the tableau held in LDS.  In front of it a backup (slab, control block, both devex weight sets): a
         // launch whose workgroups do not all become resident in time aborts mid-step, and the backup is what the
@@ -1348,12 +1353,16 @@ static int solve_once(mvx_prob *P, const mvx_smcp *parm, bool aux) {
     c.aux_ready = true;
   }
   J.sc = aux ? &c.aux : &c.main;
+  static std::atomic<bool> g_resident_token{false};
+  bool expected = false;
+  J.resident = g_resident_token.compare_exchange_strong(expected, true);
   job_begin(c, J);
   for (;;) {
     job_enqueue(c, J);
     HIPCHECK(hipStreamSynchronize(J.sc->stream));
     if (job_collect(c, J)) break;
   }
+  if (J.resident) g_resident_token.store(false);
   return J.rc;
 }
 

@@ -539,23 +539,30 @@ def test_degenerate_lps_through_the_resident_tableau_kernel(gpu, orc, case):
     path; every reduction candidate is value-initialised now.)"""
     m, n, seed, frac0 = case
     A, b, c = lpgen.degenerate_lp(m, n, seed, frac0=frac0)
-    g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
-    for P in (g, o):
-        P.simplex()
+    gpu.set_cluster(0)  # the cluster chain would take these sizes first; this test is about k_persist
+    try:
+        g, o = lpgen.load_degenerate(gpu, A, b, c), lpgen.load_degenerate(orc, A, b, c)
+        for P in (g, o):
+            P.simplex()
+    finally:
+        gpu.set_cluster(1)
     assert g.status == o.status and g.it_cnt == o.it_cnt
     assert np.array_equal(g.tableau(), o.tableau())
     for u, v in zip(g.basis(), o.basis()):
         assert np.array_equal(u, v)
 
 
-@pytest.mark.parametrize("persist", [0, 1])
-def test_short_calls_taken_over_at_their_first_pivot(gpu, orc, persist):
+@pytest.mark.parametrize("persist,cluster", [(0, 1), (1, 0), (0, 0)], ids=["cluster-chain", "resident-tableau", "two-launch"])
+def test_short_calls_taken_over_at_their_first_pivot(gpu, orc, persist, cluster):
     """A primal call starts in the fused pipeline (k_fboot does select_step's opening feasibility check and restarts the
     devex weights), the generic step closes each batch and k_fa reports the pivot limit itself: a run of short calls --
     limits 1, 2, 3, 5, 8, 13, ... -- must leave the same bits as the oracle after every call, with the two-kernel path
     (resident-tableau kernel off) and with the default choice.  The bounded columns bring flips among the first steps;
-    the last call ends on the optimum instead of the limit."""
+    the last call ends on the optimum instead of the limit.  Three ways of running primal phase 2: the cluster chain
+    (k_chain, the default), the resident-tableau kernel (k_persist: what serves small LPs when the cluster is off) and two
+    launches per chained step (k_pc / k_pr)."""
     gpu.set_persist(persist)
+    gpu.set_cluster(cluster)
     try:
         for (m, n, seed) in ((96, 400, 3), (300, 700, 11)):
             A, b, c = synth.dense_lp(m, n, seed)
@@ -575,6 +582,7 @@ def test_short_calls_taken_over_at_their_first_pivot(gpu, orc, persist):
             assert g.status == capi.OPT
     finally:
         gpu.set_persist(1)
+        gpu.set_cluster(1)
 
 
 def test_first_call_not_primal_feasible_leaves_the_fused_path_alone(gpu, orc):
