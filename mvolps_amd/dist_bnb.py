@@ -170,12 +170,14 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
     if cut_strat:
         cut_params = dict(var_strat=var_strat, cut_strat=cut_strat, quirks=quirks, lazy_pool=lazy_pool, cut_select=cut_select,
                           cut_chance=cut_chance)
+    widths = []  # nodes per round: how much of the farm a tree can keep busy (a narrow tree measures the all-reduce latency)
 
     while queue and not stop_all:
         if max_nodes > 0 and count >= max_nodes:
             hit_limit = 1
             break
         W = min(len(queue), world * per_rank)
+        widths.append(W)
         window = [queue[i] for i in range(W)]
 
         # ---- A. solve the window (bs.cpp:114-117, printInfo bs.cpp:135|151)
@@ -354,6 +356,9 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         xt = x.to(cdev)
         dist.broadcast(xt, src=inc_owner if group is None else dist.get_global_rank(group, inc_owner), group=group)
         x = xt.cpu()
+    if widths:
+        ws = sorted(widths)
+        stats["nodes_per_round"] = {"min": ws[0], "median": ws[len(ws) // 2], "max": ws[-1], "window_capacity": world * per_rank}
     nn = next_id - 1
     out_events = [(t, oid, parent[oid], branch_direction(oid), f6, f7, f8, pk) for (t, oid, f6, f7, f8, pk) in events]
     return {
