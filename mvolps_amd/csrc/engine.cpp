@@ -61,6 +61,7 @@ void launch_dboot(Ctl *, int n, hipStream_t);
 void launch_da(Ctl *, int n, hipStream_t);
 void launch_db(Ctl *, int m, int n, hipStream_t);
 void launch_select(Ctl *, hipStream_t, int slots = 1);
+int launch_dsel(Ctl *, int m, int n, hipStream_t, int slots = 1);
 void launch_select_queue(Ctl *, const BatchQueue &q, hipStream_t, int slots);
 void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1, int chained = 0);
 void launch_p1_head(Ctl *, hipStream_t);
@@ -648,12 +649,15 @@ static int chain_length(const mvx_prob *P) {
 // longest chain pays (wide 512x1024 tree: 9.1 k nodes/s unchained, 14.8 k at 4, 18.9 k at 8); where a few small
 // tableaux wait on each other's longest solve, 4 is the optimum (config-5 tree: 3.30 k, 4.40 k at 4, 4.22 k at 8).
 static int g_dchain = -1;
-static int dual_chain_length(bool wide) {
+static int dual_chain_length(bool wide, bool on_chip = false) {
   if (g_dchain < 0) {
     const char *e = std::getenv("MVX_DCHAIN");
     g_dchain = e ? std::max(1, std::min(DCH_MAX, std::atoi(e))) : 0;
   }
   if (g_dchain > 0) return g_dchain;
+  // node LPs that k_dsel takes (up to 1024 x 1024): a chained step costs a few microseconds there, the longest chain pays
+  // (config-5 tree: 5.5 k nodes/s at 4, 5.8 k at 6 and 8; wide tree 158 -> 140 ms per 2000 nodes)
+  if (on_chip) return 8;
   return wide ? 8 : 4;
 }
 
@@ -697,7 +701,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
   }
   h->rpc = sc.d_rpc;
   h->chain_max = chain_length(P);
-  h->dchain_max = dual_chain_length((size_t)(P->m + 1) * (size_t)P->ld * 8 >= ((size_t)16 << 20));
+  h->dchain_max = dual_chain_length((size_t)(P->m + 1) * (size_t)P->ld * 8 >= ((size_t)16 << 20), P->m <= 1024 && P->n <= 1024);
   h->nch = 1;
 }
 
@@ -1154,6 +1158,7 @@ static void job_enqueue(Context &c, SolveJob &J) {
       }
     } else {
       for (int k = 0; k < depth; k++) {
+        launch_dsel(sc.d_ctl, m, n, sc.stream); // a dual phase carrying on (warm starts): the chain on chip, k_select then returns
         launch_select(sc.d_ctl, sc.stream);
         ev();
         launch_update(sc.d_ctl, m_grid, n, sc.stream, 1, 1);
@@ -1571,7 +1576,7 @@ static void batch_fill_job(Ctl *h, mvx_prob *P, const mvx_smcp &parm, int njobs)
   h->fstate = F_OFF;
   h->job = -1;
   h->nch = 1;
-  h->dchain_max = dual_chain_length(njobs >= 32);
+  h->dchain_max = dual_chain_length(njobs >= 32, P->m <= 1024 && P->n <= 1024);
   take_edits(P, h);
 }
 
@@ -1688,6 +1693,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   int next_seen = 0; // the queue's hand-out counter as of the last poll
   for (;;) {
     for (int d = 0; d < depth; d++) {
+      launch_dsel(bc.d_ctl, m_max, n_max, bc.stream, Kact); // every slot whose dual phase is carrying on: its chain on chip
       launch_select_queue(bc.d_ctl, q, bc.stream, Kact);
       launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact, 1);
     }

@@ -714,6 +714,207 @@ __device__ int dual_chain(const KC &k, Ctl *c, Cand *lds, int kmax) {
   return nch;
 }
 
+struct DcSlot {
+  Cand c;
+  double pay[4];
+};
+template <int MODE>
+__device__ __forceinline__ Cand block_argbest16(Cand mine, const double (&pin)[4], double (&pout)[4], DcSlot *slots) {
+  const int lane = TIDX & 63, wave = TIDX >> 6;
+  int ol;
+  const Cand wb = wave_argbest<MODE>(mine, &ol);
+  double pv[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) pv[k] = rl_d(pin[k], ol);
+  if (lane == 0) {
+    slots[wave].c = wb;
+#pragma unroll
+    for (int k = 0; k < 4; k++) slots[wave].pay[k] = pv[k];
+  }
+  __syncthreads();
+  Cand rc{0.0, 0.0, 0, 0};
+  if (lane < 16) rc = slots[lane].c;
+  int wl;
+  const Cand win = wave_argbest<MODE>(rc, &wl);
+#pragma unroll
+  for (int k = 0; k < 4; k++) pout[k] = slots[wl].pay[k];
+  __syncthreads(); // the slots are reused by the next reduction
+  return win;
+}
+
+// ------------------------------------------------------------------ k_dsel: a dual phase that carries on, on chip
+// Every warm-started B&B child runs the dual simplex (bs.cpp:279,287), and k_select's generic stage plus dual_chain
+// re-derive everything from memory at every step -- column 0, the bounds, the objective row, the statuses carried through
+// the chain with a global load per earlier step: five dependent stages of memory round trips, 11.5 us per step; the
+// calibrated config-5 tree spends 77 % of its GPU time there (profiles/r03_config5_kernel_stats.txt).  k_dsel is launched
+// in front of k_select and takes the step over when the solve is simply carrying on in the dual phase on a node LP of up
+// to 1024 rows and 1024 columns (one row and one column per thread of the 1024): what a step changes lives in registers
+// -- basic values, bounds and dual devex weights of the rows; reduced costs, statuses and bounds of the columns --, every
+// thread's own entries of the chain's pivot columns and scaled pivot rows in LDS, so a step is two memory round trips
+// (row p, column q) and a handful of LDS exchanges, and the whole chain of up to 8 dual pivots, the first included,
+// starts from one load of the state.  Same arithmetic in the same order per entry as select_step + dual_chain: the
+// result is theirs bit for bit.  Whenever the first step is not a plain dual pivot (no infeasible row left: the phase
+// changes; no entering column: the LP is infeasible; Bland's rule in force; bound edits waiting; the pivot limit) it
+// touches nothing and k_select decides; otherwise it leaves `dsel` set and k_select returns at once.
+constexpr size_t DSEL_LDS = (size_t)2 * DCH_MAX * 1024 * 8; // the chain's history: one slot per thread, step and side
+__global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
+  extern __shared__ double dc_hist[]; // [2][DCH_MAX][1024]
+  __shared__ DcSlot s_slots[16];
+  __shared__ double s_hp[DCH_MAX], s_hq[DCH_MAX], s_misc[4];
+  __shared__ ChainStep sts[DCH_MAX]; // the chain so far (every thread holds the same values; thread 0 writes them down)
+  c += blockIdx.z;
+  if (c->done != D_RUN || c->phase != PH_DUAL || c->n_edits != 0 || c->dchain_max <= 1 || c->budget == 0 || c->pc_itlim) return;
+  if (c->stall >= c->stall_limit || c->m > 1024 || c->n > 1024 || c->T == nullptr) return;
+  const KC k = load_kc(c);
+  const int m = k.m, n = k.n, t = TIDX, kmax = c->dchain_max;
+  const size_t ld = (size_t)k.ld;
+  const double *const T = k.T;
+  const int budget = c->budget, stall_limit = c->stall_limit;
+  const int i = 1 + t, j = 1 + t;
+  const bool ract = (i <= m), cact = (j <= n);
+  const int ic = ract ? i : m, jc = cact ? j : n;
+#define DC_HC(L) dc_hist[(size_t)(L) * 1024 + t]
+#define DC_HS(L) dc_hist[(size_t)(DCH_MAX + (L)) * 1024 + t]
+  // ---- the state as it stands
+  double be = T[(size_t)ic * ld], d = T[jc];
+  double lb = k.blb[ic], ub = k.bub[ic], dw = k.dw[ic];
+  int f = cact ? k.nflag[jc] : MVX_NS;
+  double nlbj = k.nlb[jc], nubj = k.nub[jc]; // bounds of the columns as the chain leaves them (x_q of a later step)
+  int stall = c->stall;
+  int nch = 0, p0 = 0, q0 = 0, lf0 = 0, p_up0 = 0;
+  double piv0 = 1.0, xq0 = 0.0, bound0 = 0.0;
+  for (int kk = 0; kk < kmax; kk++) {
+    if (kk >= 1 && ((budget >= 0 && budget < kk + 1) || stall >= stall_limit)) break;
+    // ---- leaving row (dev_infeas_row on the carried values)
+    Cand rb{0.0, 0.0, 0, 0};
+    const double tolb = k.tol_bnd;
+    if (ract) {
+      double viol = 0.0;
+      int up = 0;
+      if (lb > -INFINITY && be < lb - tolb * (1.0 + fabs(lb))) viol = lb - be;
+      if (ub < INFINITY && be > ub + tolb * (1.0 + fabs(ub))) {
+        viol = be - ub;
+        up = 1;
+      }
+      if (viol > 0.0) rb = Cand{xdiv(viol * viol, dw), 0.0, i, up};
+    }
+    double rp[4] = {be, lb, ub, dw}, ro[4];
+    const Cand rw = block_argbest16<0>(rb, rp, ro, s_slots);
+    if (rw.idx == 0) break; // primal feasible: k_select changes phase
+    const int p = rw.idx, p_up = rw.aux;
+    const double bp = ro[0], plb = ro[1], pub = ro[2], wp = ro[3];
+    // ---- row p as of step kk: its entries of the earlier pivot columns come from the thread that owns the row
+    double a = T[(size_t)p * ld + jc];
+    if (i == p)
+      for (int l = 0; l < kk; l++) s_hp[l] = DC_HC(l);
+    __syncthreads();
+    for (int l = 0; l < kk; l++) a = chain_apply(sts[l], p, jc, a, s_hp[l], DC_HS(l));
+    // dual ratio test (dev_dual_ratio on the carried values)
+    Cand best{0.0, 0.0, 0, 0};
+    const double tp = k.tol_piv, sgn = k.sgn;
+    if (cact && f != MVX_NS) {
+      const double aa = p_up ? -a : a;
+      const double dd = sgn * d;
+      double r = 0.0;
+      bool ok = false;
+      if (aa > tp && (f == MVX_NL || f == MVX_NF)) {
+        r = (f == MVX_NF) ? fabs(dd) : (dd < 0.0 ? -dd : 0.0);
+        ok = true;
+      } else if (aa < -tp && (f == MVX_NU || f == MVX_NF)) {
+        r = (f == MVX_NF) ? fabs(dd) : (dd > 0.0 ? dd : 0.0);
+        ok = true;
+      }
+      if (ok) {
+        const double mag = fabs(a);
+        best = Cand{xdiv(r, mag), mag, j, 0};
+      }
+    }
+    double qp[4] = {a, d, nlbj, nubj}, qo[4];
+    const Cand qw = block_argbest16<1>(best, qp, qo, s_slots);
+    if (qw.idx == 0) break; // no entering column: k_select reports it
+    const int q = qw.idx;
+    const double apq = qo[0], dq = qo[1], lbq = qo[2], ubq = qo[3];
+    // ---- column q as of step kk: its entries of the earlier scaled rows (and its status) come from its owner
+    double cq = T[(size_t)ic * ld + q];
+    if (j == q) {
+      for (int l = 0; l < kk; l++) s_hq[l] = DC_HS(l);
+      s_misc[0] = (double)f;
+    }
+    __syncthreads();
+    const int fq = (int)s_misc[0];
+    for (int l = 0; l < kk; l++) cq = chain_apply(sts[l], ic, q, cq, DC_HC(l), s_hq[l]);
+    const double bound = p_up ? pub : plb;
+    const int lf = dev_leave_flag(plb, pub, p_up);
+    const double s0 = xdiv(bp - bound, apq);
+    const double xq = dev_nb_value(fq, lbq, ubq);
+    const ChainStep stk{p, q, lf, apq, xq, s0};
+    // step 0 goes where the generic stage puts its step (colq / srow), the following ones where dual_chain puts them
+    double *const ck = (kk == 0) ? k.colq : c->colqk[kk], *const sk = (kk == 0) ? k.srow : c->srowk[kk];
+    // the rows: pivot column out, dual devex weights (select_step's pass), basic values and bounds after the step
+    if (ract) {
+      ck[i] = cq;
+      if (i == p) {
+        const double cc = xdiv(wp, apq * apq);
+        dw = cc > 1.0 ? cc : 1.0;
+      } else {
+        const double r = xdiv(cq, apq);
+        const double cc = r * r * wp;
+        if (cc > dw) dw = cc;
+      }
+      be = chain_apply(stk, i, 0, be, cq, s0);
+      if (i == p) {
+        lb = lbq;
+        ub = ubq;
+      }
+    }
+    DC_HC(kk) = cq;
+    // the columns: scaled pivot row out, reduced costs and statuses after the step
+    const double sj = xdiv(a, apq);
+    if (cact) sk[j] = sj;
+    d = chain_apply(stk, 0, jc, d, dq, sj);
+    if (cact && j == q) {
+      f = lf;
+      nlbj = plb;
+      nubj = pub;
+    }
+    DC_HS(kk) = sj;
+    stall = (qw.k1 <= DEGEN_TOL) ? stall + 1 : 0;
+    if (kk == 0) {
+      p0 = p; q0 = q; lf0 = lf; piv0 = apq; xq0 = xq; p_up0 = p_up; bound0 = bound;
+    }
+    if (t == 0) {
+      sts[kk] = stk;
+      ck[0] = dq;
+      sk[0] = s0;
+      c->ch_p[kk] = p;
+      c->ch_q[kk] = q;
+      c->ch_lf[kk] = lf;
+      c->ch_piv[kk] = apq;
+      c->ch_xq[kk] = xq;
+      c->ch_s0[kk] = s0;
+    }
+    nch = kk + 1;
+  }
+#undef DC_HC
+#undef DC_HS
+  if (nch == 0) return; // not a plain dual pivot: nothing has been touched, k_select decides
+  if (ract) k.dw[i] = dw; // the weights as the chain leaves them, where the next step reads them
+  if (t == 0) {
+    c->stall = stall;
+    c->nch = nch;
+    c->dsel = 1; // k_select has nothing to do for this step
+    // what dev_prepare_pivot publishes
+    c->step = ST_PIVOT;
+    c->p = p0;
+    c->q = q0;
+    c->p_up = p_up0;
+    c->piv = piv0;
+    c->bound = bound0;
+    c->xq = xq0;
+    c->leave_flag = lf0;
+  }
+}
+
 // ---------------------------------------------------------------------------- k_select
 // Device-side restatement of orc_simplex's round loop + one pricing / ratio-test step.
 __device__ void select_step(Ctl *c, Cand *lds) {
@@ -907,6 +1108,11 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
   __shared__ Cand lds[17];
   __shared__ int s_job;
   c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
+  if (c->dsel) { // k_dsel has prepared this step (a dual phase carrying on): nothing to select
+    __syncthreads();
+    if (TIDX == 0) c->dsel = 0;
+    return;
+  }
   if (q.jobs && c->done != D_RUN) {
     // this slot's solve has ended (or it never had one): hand the finished job over and pull the next
     const int old = c->job;
@@ -3790,6 +3996,22 @@ void launch_db(Ctl *d_ctl, int m, int n, hipStream_t s) {
   DB_CASE(16, 2) DB_CASE(8, 2) DB_CASE(4, 2) DB_CASE(32, 2)
 #undef DB_CASE
   std::abort(); // unreachable
+}
+// k_dsel in front of k_select (node LPs of up to 1024 rows and columns); MVX_DSEL=0 or a refused LDS attribute: never
+int launch_dsel(Ctl *d_ctl, int m, int n, hipStream_t s, int slots) {
+  static int state = -1; // -1 not tried, 0 off, 1 on
+  if (state < 0) {
+    const char *e = std::getenv("MVX_DSEL");
+    if (e && e[0] == '0') state = 0;
+    else if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dsel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DSEL_LDS) == hipSuccess) state = 1;
+    else {
+      (void)hipGetLastError();
+      state = 0;
+    }
+  }
+  if (state != 1 || m > 1024 || n > 1024) return 0;
+  hipLaunchKernelGGL(k_dsel, dim3(1, 1, slots), dim3(1024), DSEL_LDS, s, d_ctl);
+  return 1;
 }
 void launch_select(Ctl *d_ctl, hipStream_t s, int slots) {
   BatchQueue q{};

@@ -131,6 +131,7 @@ struct Ctl {
   double ch_delta[KCH]; // bound flips: the entering variable's move
   int pc_itlim;         // k_chain: the pivot limit is reached once the pending chain is applied and an entering column is still
                         // on offer: the generic step that closes the batch reports it without pricing again
+  int dsel;             // k_dsel has prepared the coming step (a dual phase carrying on): the k_select that follows returns at once
   int cl_abort;         // k_chain gave up waiting for its peer workgroups: the chain was dropped, nothing was changed
   unsigned long long *dbg; // diagnostic phase stamps of k_fcs (MVX_FCS_DBG=1), nullptr otherwise
 };

@@ -40,6 +40,15 @@ int mvx_gmi_cuts(const mvx_prob *P, int repaired, const int *cols, int count, do
   (void)P; (void)repaired; (void)cols; (void)count; (void)vals; (void)rhs; (void)ok;
   return -1; /* no batch entry on this side: the harness runs without cuts */
 }
+int mvx_gmi_cuts_many(const mvx_prob *const *Ps, int repaired, const int *cols, int count, double *vals, double *rhs, int *ok) {
+  (void)Ps; (void)repaired; (void)cols; (void)count; (void)vals; (void)rhs; (void)ok;
+  return -1;
+}
+/* the bulk read printInfo uses: read by several host threads at once in the window driver */
+void mvx_get_col_prim_all(const mvx_prob *P, double *x) {
+  const int n = orc_get_num_cols(CO(P));
+  for (int j = 1; j <= n; j++) x[j] = orc_get_col_prim(CO(P), j);
+}
 /* model construction for the harness */
 void mvx_set_obj_dir(mvx_prob *P, int dir) { orc_set_obj_dir(O(P), dir); }
 int mvx_add_cols(mvx_prob *P, int ncs) { return orc_add_cols(O(P), ncs); }
