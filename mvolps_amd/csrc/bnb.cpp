@@ -782,8 +782,17 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
   // one round finish (few batch slots busy), the next round's batch is already running on another batch context.
   std::deque<std::unique_ptr<Round>> flight;
   std::unordered_map<const void *, const Round *> inflight; // child handle -> the round that is solving it
-  size_t depth = 2;
-  if (const char *e = std::getenv("MVX_BNB_DEPTH")) depth = (size_t)std::max(1, std::min(4, std::atoi(e)));
+  // Experiment knobs (off by default).  MVX_BNB_CHUNK=<c>: a replay's branchings leave as up to four rounds (chunks of at
+  // least c branchings, in queue order), each one batched solve on its own worker; MVX_BNB_PREFIX=1: the next window
+  // takes the queue's nodes only as far as their solves have ended, so one slow child holds back the nodes behind it in
+  // its chunk and nothing else.  On the config-5 tree (a few tens of nodes wide, two thirds of a whole-round batch's
+  // slot-launches idle behind its slowest LP: scripts/roundstats.py) this was measured SLOWER -- 2.86 s whole rounds,
+  // 3.35 s with chunks of 8, 3.43 s with chunks of 2: more and smaller batches pay more fixed cost per batch, and the
+  // dispatch of their tiny launches is what the GPU runs out of, not slots.  The wide tree does not care (104-117 ms).
+  size_t depth = 2, chunk = (size_t)1 << 30;
+  if (const char *e = std::getenv("MVX_BNB_DEPTH")) depth = (size_t)std::max(1, std::min(32, std::atoi(e)));
+  if (const char *e = std::getenv("MVX_BNB_CHUNK")) chunk = (size_t)std::max(1, std::atoi(e));
+  const bool prefix = std::getenv("MVX_BNB_PREFIX") && std::atoi(std::getenv("MVX_BNB_PREFIX")) != 0;
   CutPool pool(api); // persistent across nodes in bug-compatible mode (cut.h:15-23)
   const bool timing = std::getenv("MVX_BNB_TIMING") != nullptr;
   double tA = 0, tB = 0, tB_info = 0, tB_clone = 0, tB_cuts = 0, tB_rcuts = 0, tWait = 0;
@@ -833,11 +842,19 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
       break;
     }
     double t0 = now();
-    const size_t W = std::min(leafContainer.size(), (size_t)prm.window);
-    // the window may reach into the children that are still being solved
+    size_t W = std::min(leafContainer.size(), (size_t)prm.window);
+    // The window may reach into the children that are still being solved: it ends in front of the first node whose
+    // round has not finished (rounds are in queue order, so every older one has been booked by then), and waits
+    // only when that node is the queue's head.  Same nodes in the same order as one by one -- only the grouping moves.
     for (size_t w = 0; w < W; w++) {
       auto it = inflight.find(leafContainer[w]->prob);
-      if (it != inflight.end()) finalize_through(it->second);
+      if (it == inflight.end()) continue;
+      const Round *R = it->second;
+      if (prefix && w > 0 && R->fut.valid() && R->fut.wait_for(std::chrono::seconds(0)) != std::future_status::ready) {
+        W = w;
+        break;
+      }
+      finalize_through(R);
     }
     // A. solve the window (bs.cpp:114-117).  The reference copies the node's problem into the scratch
     // `a` and solves the copy; the node is discarded after this step either way, so its own clone is
@@ -997,58 +1014,73 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     }
     rec.sink = nullptr;
     tB += now() - t0;
-    // C. every child of this round is an independent LP (bs.cpp:279,287): one batched solve, on the worker
-    // thread; then, for the children found infeasible (or unbounded), the re-solve bs.cpp:117 will ask for when they are
+    // C. every child of this round is an independent LP (bs.cpp:279,287): batched solves on worker threads; then, for
+    // the children found infeasible (or unbounded), the re-solve bs.cpp:117 will ask for when they are
     // popped (it depends on nothing that happens in between), so that popping never has to solve.
-    while (flight.size() >= depth) finalize_oldest(); // at most `depth` rounds in flight; events stay in round order
-    for (auto &br : branches) {
-      cur.kids.push_back(br.S2->prob);
-      cur.kids.push_back(br.S3->prob);
-    }
-    cur.active = true;
-    flight.push_back(std::make_unique<Round>(std::move(cur)));
-    Round &pend = *flight.back();
-    if (!pend.kids.empty()) {
-      Round *R = &pend;
-      for (void *k : R->kids) inflight.emplace(k, R);
-      const size_t nk = R->kids.size();
-      R->after1.assign(nk, 0);
-      R->repiv.assign(nk, -1);
-      R->obj1.assign(nk, 0.0);
-      // the children go through the engine's batch entry in two halves on two threads: the host side of one batch
-      // (control-block uploads, polls, result mirrors) overlaps the kernels of the other
-      auto solve_range = [api, R](size_t lo, size_t hi) {
-        if (hi <= lo) return;
-        api->simplex_batch(R->kids.data() + lo, (int)(hi - lo), nullptr, nullptr);
-        std::vector<void *> again;
-        std::vector<size_t> idx;
-        for (size_t k = lo; k < hi; k++) {
-          R->after1[k] = api->get_it_cnt(R->kids[k]);
-          R->obj1[k] = api->get_obj_val(R->kids[k]);
-          const int st1 = api->get_status(R->kids[k]);
-          if (st1 == MVX_NOFEAS || st1 == MVX_UNBND) { // a re-solve of these may pivot on (fresh devex weights)
-            again.push_back(R->kids[k]);
-            idx.push_back(k);
+    // The replay is cut into rounds of whole nodes: chunk k holds the events of its nodes and their branchings.
+    {
+      const size_t nb = branches.size();
+      const size_t per = std::max(chunk, (nb + 3) / 4);
+      const size_t nchunks = nb == 0 ? 1 : (nb + per - 1) / per;
+      size_t ev_lo = 0;
+      for (size_t ck = 0; ck < nchunks; ck++) {
+        const size_t b_lo = ck * per, b_hi = std::min(nb, b_lo + per);
+        const size_t ev_hi = (ck + 1 == nchunks) ? cur.node_events.size() : branches[b_hi - 1].slot + 1;
+        auto part = std::make_unique<Round>();
+        for (size_t e = ev_lo; e < ev_hi; e++) part->node_events.push_back(std::move(cur.node_events[e]));
+        for (size_t bi = b_lo; bi < b_hi; bi++) {
+          Branch br = branches[bi];
+          br.slot -= ev_lo;
+          part->kids.push_back(br.S2->prob);
+          part->kids.push_back(br.S3->prob);
+          part->branches.push_back(std::move(br));
+        }
+        ev_lo = ev_hi;
+        part->active = true;
+        while (flight.size() >= depth) finalize_oldest(); // at most `depth` rounds in flight; events stay in round order
+        flight.push_back(std::move(part));
+        Round *R = flight.back().get();
+        if (R->kids.empty()) continue;
+        for (void *k : R->kids) inflight.emplace(k, R);
+        const size_t nk = R->kids.size();
+        R->after1.assign(nk, 0);
+        R->repiv.assign(nk, -1);
+        R->obj1.assign(nk, 0.0);
+        auto solve_range = [api, R](size_t lo, size_t hi) {
+          if (hi <= lo) return;
+          api->simplex_batch(R->kids.data() + lo, (int)(hi - lo), nullptr, nullptr);
+          std::vector<void *> again;
+          std::vector<size_t> idx;
+          for (size_t k = lo; k < hi; k++) {
+            R->after1[k] = api->get_it_cnt(R->kids[k]);
+            R->obj1[k] = api->get_obj_val(R->kids[k]);
+            const int st1 = api->get_status(R->kids[k]);
+            if (st1 == MVX_NOFEAS || st1 == MVX_UNBND) { // a re-solve of these may pivot on (fresh devex weights)
+              again.push_back(R->kids[k]);
+              idx.push_back(k);
+            }
           }
-        }
-        if (!again.empty()) {
-          api->simplex_batch(again.data(), (int)again.size(), nullptr, nullptr);
-          for (size_t t = 0; t < idx.size(); t++) R->repiv[idx[t]] = api->get_it_cnt(again[t]) - R->after1[idx[t]];
-        }
-      };
-      const bool two = nk >= 32 && !std::getenv("MVX_BNB_ONE_WORKER");
-      auto work = [solve_range, nk, two]() {
-        if (!two) {
-          solve_range(0, nk);
-          return;
-        }
-        const size_t half = (nk / 2 + 1) & ~(size_t)1; // siblings stay together
-        auto other = std::async(std::launch::async, solve_range, half, nk);
-        solve_range(0, half);
-        other.get();
-      };
-      if (prm.window > 1 && !std::getenv("MVX_BNB_SYNC")) pend.fut = std::async(std::launch::async, work);
-      else work();
+          if (!again.empty()) {
+            api->simplex_batch(again.data(), (int)again.size(), nullptr, nullptr);
+            for (size_t t = 0; t < idx.size(); t++) R->repiv[idx[t]] = api->get_it_cnt(again[t]) - R->after1[idx[t]];
+          }
+        };
+        // a wide chunk goes through the engine's batch entry in two halves on two threads: the host side of one batch
+        // (control-block uploads, polls, result mirrors) overlaps the kernels of the other
+        const bool two = nk >= 32 && !std::getenv("MVX_BNB_ONE_WORKER");
+        auto work = [solve_range, nk, two]() {
+          if (!two) {
+            solve_range(0, nk);
+            return;
+          }
+          const size_t half = (nk / 2 + 1) & ~(size_t)1; // siblings stay together
+          auto other = std::async(std::launch::async, solve_range, half, nk);
+          solve_range(0, half);
+          other.get();
+        };
+        if (prm.window > 1 && !std::getenv("MVX_BNB_SYNC")) R->fut = std::async(std::launch::async, work);
+        else work();
+      }
     }
     leafContainer.erase(leafContainer.begin(), leafContainer.begin() + (long)processed);
   }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 
 #include "engine.hpp"
@@ -92,8 +93,22 @@ void mvx_delete_prob(mvx_prob *P) {
   delete P;
 }
 
+namespace {
+// MVX_COPY_TIMING=1: where a clone's host time goes (printed when the library unloads)
+struct CopyTiming {
+  bool on = std::getenv("MVX_COPY_TIMING") != nullptr;
+  double host = 0, engine = 0;
+  long calls = 0;
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  ~CopyTiming() {
+    if (on && calls) std::fprintf(stderr, "mvx_copy_prob: %ld calls, host fields %.1f us, engine_copy %.1f us each\n", calls, 1e6 * host / calls, 1e6 * engine / calls);
+  }
+} g_copy_timing;
+} // namespace
+
 void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   if (dst == src) fault("copy_prob: dst == src");
+  const double t0 = g_copy_timing.on ? CopyTiming::now() : 0.0;
   mvx::release_device(dst);
   // host model: matrix rows are shared (immutable, copy-on-write in set_mat_row)
   dst->m = src->m; dst->n = src->n; dst->dir = src->dir;
@@ -111,7 +126,13 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   std::memcpy(dst->last_tol, src->last_tol, sizeof(dst->last_tol));
   dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
   dst->sol_fresh = src->sol_fresh; dst->beta = src->beta; dst->dj = src->dj;
+  const double t1 = g_copy_timing.on ? CopyTiming::now() : 0.0;
   mvx::engine_copy(dst, src);
+  if (g_copy_timing.on) {
+    g_copy_timing.host += t1 - t0;
+    g_copy_timing.engine += CopyTiming::now() - t1;
+    g_copy_timing.calls++;
+  }
 }
 
 void mvx_set_obj_dir(mvx_prob *P, int dir) {

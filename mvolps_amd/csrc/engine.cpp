@@ -216,7 +216,7 @@ static void init_solve_ctx(SolveCtx &sc) {
   HIPCHECK(hipEventCreate(&sc.ev_a));
   HIPCHECK(hipEventCreate(&sc.ev_b));
   HIPCHECK(hipMalloc((void **)&sc.d_xg, XG_BYTES + 256));
-  HIPCHECK(hipMemset(sc.d_xg, 0, XG_BYTES + 256));
+  HIPCHECK(hipMemsetAsync(sc.d_xg, 0, XG_BYTES + 256, sc.stream)); // ordered with the launches that use it (a null-stream memset is not)
   sc.d_xabort = (int *)((unsigned char *)sc.d_xg + XG_BYTES);
 }
 
@@ -421,9 +421,19 @@ static void bind_slab(mvx_prob *P, void *slab, int m_cap, int ld) {
   P->d_nflag = (int *)(b + L.o_nflag);
   P->d_nlb = (double *)(b + L.o_nlb);
   P->d_nub = (double *)(b + L.o_nub);
+  // debugging aid: MVX_BIND_FILL="t,a" fills the tableau region with byte t and the small arrays with byte a at every
+  // binding (-1: leave), on the main stream (the caller's upload or clone follows on it)
+  static const char *bf = std::getenv("MVX_BIND_FILL");
+  if (bf) {
+    int t = -1, a = -1;
+    std::sscanf(bf, "%d,%d", &t, &a);
+    hipStream_t st = ctx().main.stream;
+    if (t >= 0) HIPCHECK(hipMemsetAsync(b + L.o_T, t & 255, L.o_bvar - L.o_T, st));
+    if (a >= 0) HIPCHECK(hipMemsetAsync(b + L.o_bvar, a & 255, L.total - L.o_bvar, st));
+  }
 }
 
-static const size_t SLAB_CACHE_LIMIT = (size_t)8 << 30; // idle bytes kept for reuse
+static const size_t SLAB_CACHE_LIMIT = (size_t)32 << 30; // idle bytes kept for reuse (of 288 GB)
 
 // caller holds the cache lock.  Give idle memory back to the driver: every idle slab that is not part of an arena, and
 // every arena whose slabs are all idle; stops once the idle bytes are at or below `keep`.
@@ -457,6 +467,19 @@ static void slab_trim(SlabCache &sc, size_t keep) {
   }
 }
 
+// Fresh device memory is not zeroed by the driver (it holds whatever the last process left there), and a slab has
+// regions no kernel of a solve writes before the first whole-slab clone reads them (spare rows for cuts, the padding of
+// a row, array tails): they are never part of a result, but they travel with every clone, so they start as zeros.
+// MVX_SLAB_FILL=<byte> fills with that byte instead (255: NaN patterns, to flush out a read of such a region).
+static void slab_fill(void *p, size_t bytes) {
+  static hipStream_t fill_stream = nullptr;
+  static const int fill = std::getenv("MVX_SLAB_FILL") ? std::atoi(std::getenv("MVX_SLAB_FILL")) : 0;
+  if (fill < 0) return;
+  if (!fill_stream) HIPCHECK(hipStreamCreateWithFlags(&fill_stream, hipStreamNonBlocking));
+  HIPCHECK(hipMemsetAsync(p, fill & 255, bytes, fill_stream));
+  HIPCHECK(hipStreamSynchronize(fill_stream));
+}
+
 // nullptr when the device is out of memory even after the idle slabs have been given back (mvx_last_error() then
 // reads MVX_ENOMEM); never aborts
 static void *slab_alloc(Context &c, size_t bytes) {
@@ -473,8 +496,22 @@ static void *slab_alloc(Context &c, size_t bytes) {
   }
   void *p = nullptr;
   if (bytes <= ((size_t)64 << 20)) {
-    const size_t count = std::min<size_t>(32, std::max<size_t>(2, ((size_t)256 << 20) / bytes));
-    if (hipMalloc(&p, bytes * count) == hipSuccess) {
+    // A size class doubles each time it runs dry (32, 32, 64, 128, ... slabs, at most 16 GB at once): a B&B frontier of
+    // a thousand 4 MB node tableaux is six allocations, not thirty.  hipMalloc beside two threads that launch and wait
+    // was measured at 60-130 us per CLONE in arenas of 32 (milliseconds per call), against 12 us when the process is idle.
+    const size_t least = std::min<size_t>(32, std::max<size_t>(2, ((size_t)256 << 20) / bytes));
+    size_t have = 0;
+    for (const Arena &ar : sc.arenas)
+      if (ar.base && ar.slab_bytes == bytes) have += (size_t)ar.count;
+    size_t count = std::min(std::max(least, have), std::max<size_t>(least, ((size_t)16 << 30) / bytes));
+    if (hipMalloc(&p, bytes * count) != hipSuccess) {
+      (void)hipGetLastError();
+      count = least;
+      p = nullptr;
+      if (hipMalloc(&p, bytes * count) != hipSuccess) p = nullptr;
+    }
+    if (p) {
+      slab_fill(p, bytes * count);
       Arena ar;
       ar.base = p;
       ar.slab_bytes = bytes;
@@ -493,10 +530,16 @@ static void *slab_alloc(Context &c, size_t bytes) {
     (void)hipGetLastError();
     p = nullptr;
   }
-  if (hipMalloc(&p, bytes) == hipSuccess) return p;
+  if (hipMalloc(&p, bytes) == hipSuccess) {
+    slab_fill(p, bytes);
+    return p;
+  }
   (void)hipGetLastError();
   slab_trim(sc, 0); // give everything idle back and retry once
-  if (hipMalloc(&p, bytes) == hipSuccess) return p;
+  if (hipMalloc(&p, bytes) == hipSuccess) {
+    slab_fill(p, bytes);
+    return p;
+  }
   (void)hipGetLastError();
   g_last_error.store(MVX_ENOMEM);
   return nullptr;
@@ -695,6 +738,7 @@ static void fill_ctl(SolveCtx &sc, mvx_prob *P, Ctl *h) {
       if (std::getenv("MVX_FCS_DBG")) {
         HIPCHECK(hipMalloc((void **)&dbg, (size_t)KCH * 16 * 8));
         HIPCHECK(hipMemset(dbg, 0, (size_t)KCH * 16 * 8));
+        HIPCHECK(hipDeviceSynchronize());
       }
     }
     h->dbg = dbg;
@@ -1440,11 +1484,23 @@ static bool refresh_tableau(mvx_prob *P) {
 }
 
 // the counter / residual / refresh step that follows every solve (oracle: orc_simplex)
+// scripts/bnbrepeat.py: [0] tableau refreshes, [1] residual looks, [2] single-handle solves, [3] batch calls, [4] jobs a batch
+// handed to the single-handle path (neither primal nor dual feasible)
+static std::atomic<long long> g_dbg[8];
+extern "C" void mvx_debug_counters(long long *out, int reset) {
+  for (int k = 0; k < 8; k++) {
+    out[k] = g_dbg[k].load();
+    if (reset) g_dbg[k].store(0);
+  }
+}
+
 static int after_solve(mvx_prob *P, const mvx_smcp *parm, int rc, int pivots) {
   P->piv_since_check += pivots;
   if (rc == 0 && P->status == MVX_OPT && P->piv_since_check >= g_check_every) {
     P->piv_since_check = 0;
+    g_dbg[1]++;
     if (row_residual_sample(P, REFRESH_SAMPLE_ROWS) > g_refresh_tol && refresh_tableau(P)) {
+      g_dbg[0]++;
       const int before = P->it_cnt;
       // the rebuilt tableau has not been looked at by anything yet: the simplex runs on it whatever the status says (the
       // oracle's simplex_once has no "already solved" shortcut) -- it may be infeasible or non-optimal beyond the
@@ -1459,6 +1515,7 @@ static int after_solve(mvx_prob *P, const mvx_smcp *parm, int rc, int pivots) {
 
 static int engine_simplex_on(mvx_prob *P, const mvx_smcp *parm, bool aux) {
   const int before = P->it_cnt;
+  g_dbg[2]++;
   const int rc = solve_once(P, parm, aux);
   return after_solve(P, parm, rc, P->it_cnt - before);
 }
@@ -1483,8 +1540,10 @@ struct BatchCtx {
   Ctl *d_ctl = nullptr, *h_ctl = nullptr;   // slot control blocks (host copy: the idle pattern)
   Ctl *d_jobs = nullptr, *h_jobs = nullptr; // job control blocks
   Ctl *h_fill = nullptr;                    // slot control blocks read back for the tail compaction
+  hipEvent_t poll_ev = nullptr;             // follows each poll's copies on `stream`
   SlotScratch *d_sp = nullptr, *h_sp = nullptr;
-  int *d_cnt = nullptr, *h_cnt = nullptr; // [0] next job, [1] finished jobs
+  int *d_cnt = nullptr, *h_cnt = nullptr; // [0] next job, [1] finished jobs, [2] rounds launched, [3] round of the last job's end
+  int pred_rounds = 16;                   // rounds the previous batch on this context needed
   unsigned char *scratch = nullptr;
   size_t scratch_stride = 0;
   unsigned char *d_stage = nullptr, *h_stage = nullptr; // one staging area per JOB
@@ -1493,7 +1552,7 @@ struct BatchCtx {
 // Two batch contexts (stream, slot control blocks, scratch, staging): two host threads can each drive a batched solve
 // at the same time -- the B&B driver splits a round's children over two workers, so that the host side of one batch
 // (uploads, polls, result mirrors) overlaps the kernels of the other.
-constexpr int N_BATCH_CTX = 4;
+constexpr int N_BATCH_CTX = 8;
 static BatchCtx g_batch[N_BATCH_CTX];
 static std::mutex g_batch_mu[N_BATCH_CTX];
 static void sync_batch_stream() {
@@ -1504,6 +1563,7 @@ static int g_batch_slots = 64;
 
 static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
   if (!bc.stream) HIPCHECK(hipStreamCreateWithFlags(&bc.stream, hipStreamNonBlocking));
+  if (!bc.poll_ev) HIPCHECK(hipEventCreateWithFlags(&bc.poll_ev, hipEventDisableTiming));
   if (slots <= bc.slots && jobs <= bc.jobs && m_cap <= bc.m_cap && ld <= bc.ld) return;
   HIPCHECK(hipStreamSynchronize(bc.stream));
   if (bc.d_ctl) HIPCHECK(hipFree(bc.d_ctl));
@@ -1530,7 +1590,8 @@ static void ensure_batch(BatchCtx &bc, int slots, int jobs, int m_cap, int ld) {
   HIPCHECK(hipMalloc((void **)&bc.d_sp, sizeof(SlotScratch) * bc.slots));
   HIPCHECK(hipHostMalloc((void **)&bc.h_sp, sizeof(SlotScratch) * bc.slots));
   HIPCHECK(hipMalloc((void **)&bc.d_cnt, sizeof(int) * 4));
-  HIPCHECK(hipHostMalloc((void **)&bc.h_cnt, sizeof(int) * 4));
+  HIPCHECK(hipMemsetAsync(bc.d_cnt, 0, sizeof(int) * 4, bc.stream)); // on the batch's own stream: a null-stream memset is not ordered with it
+  HIPCHECK(hipHostMalloc((void **)&bc.h_cnt, sizeof(int) * 8));
   const size_t s_row = align_up((size_t)(bc.m_cap + 1) * 8, 256), s_col = align_up((size_t)bc.ld * 8, 256);
   const size_t s_var = align_up((size_t)(bc.m_cap + bc.ld + 1) * 8, 256);
   const size_t s_chain = (size_t)(DCH_MAX - 1) * (s_row + s_col);
@@ -1670,16 +1731,17 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     which = 0;
   }
   BatchCtx &bc = g_batch[which];
+  g_dbg[3]++;
   const int njobs = (int)pending.size();
   const int K = std::min(njobs, g_batch_slots);
   ensure_batch(bc, K, njobs, m_cap, ld);
   // edits queued on the main stream (bound changes, clones) must be visible to the batch stream
   HIPCHECK(hipStreamSynchronize(c.main.stream));
   for (int j = 0; j < njobs; j++) batch_fill_job(&bc.h_jobs[j], probs[pending[(size_t)j]], parm, njobs);
-  bc.h_cnt[0] = bc.h_cnt[1] = 0;
+  bc.h_cnt[0] = bc.h_cnt[1] = bc.h_cnt[2] = bc.h_cnt[3] = 0;
   HIPCHECK(hipMemcpyAsync(bc.d_jobs, bc.h_jobs, sizeof(Ctl) * (size_t)njobs, hipMemcpyHostToDevice, bc.stream));
   HIPCHECK(hipMemcpyAsync(bc.d_ctl, bc.h_ctl, sizeof(Ctl) * (size_t)K, hipMemcpyHostToDevice, bc.stream)); // every slot idle
-  HIPCHECK(hipMemcpyAsync(bc.d_cnt, bc.h_cnt, sizeof(int) * 2, hipMemcpyHostToDevice, bc.stream));
+  HIPCHECK(hipMemcpyAsync(bc.d_cnt, bc.h_cnt, sizeof(int) * 4, hipMemcpyHostToDevice, bc.stream));
   BatchQueue q;
   q.jobs = bc.d_jobs;
   q.scratch = bc.d_sp;
@@ -1687,27 +1749,45 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   q.stage = bc.d_stage;
   q.stage_stride = bc.stage_stride;
   q.count = njobs;
-  // queue-ahead depth per poll: the slots refill themselves, so a poll only has to notice the end
-  int depth = njobs <= 2 ? 8 : 16;
+  // Rounds queued ahead of the host.  The slots refill themselves, so a poll only has to notice the end; every round
+  // queued past the end is three launches that start only to leave (~12 us), and every poll the stream waits for is a
+  // host round trip with the GPU idle (~20 us).  So the polls are pipelined: burst k is queued BEFORE the host looks at
+  // the poll that followed burst k-1 -- the stream never runs dry, at the price of at most one short burst of empty
+  // rounds.  MVX_BATCH_FIRST / MVX_BATCH_BURST: rounds in the first / in every later burst (8 / 4; sweeps of 4..16 and
+  // 2..8 are within the noise of one another).  MVX_BATCH_PRED=1 sizes the first burst by the previous batch on this
+  // context (the device records the round in which the last job ended): measured no better, a poll early on lets the
+  // tail shrink sooner.
+  static const bool predict = std::getenv("MVX_BATCH_PRED") && std::atoi(std::getenv("MVX_BATCH_PRED")) != 0;
+  static const int later = std::getenv("MVX_BATCH_BURST") ? std::max(1, std::min(64, std::atoi(std::getenv("MVX_BATCH_BURST")))) : 4;
   int Kact = K; // slots launched: all of them while the queue has work, the occupied ones once it is drained
-  int next_seen = 0; // the queue's hand-out counter as of the last poll
-  for (;;) {
-    for (int d = 0; d < depth; d++) {
+  auto launch_rounds = [&](int rounds) {
+    for (int d = 0; d < rounds; d++) {
       launch_dsel(bc.d_ctl, m_max, n_max, bc.stream, Kact); // every slot whose dual phase is carrying on: its chain on chip
       launch_select_queue(bc.d_ctl, q, bc.stream, Kact);
       launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact, 1);
     }
-    HIPCHECK(hipMemcpyAsync(bc.h_cnt + 2, bc.d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, bc.stream));
-    const bool drained_before = next_seen >= njobs; // as of the previous poll: no slot can pull a job any more
-    if (drained_before && Kact > 1)
-      HIPCHECK(hipMemcpyAsync(bc.h_fill, bc.d_ctl, sizeof(Ctl) * (size_t)Kact, hipMemcpyDeviceToHost, bc.stream));
-    HIPCHECK(hipStreamSynchronize(bc.stream));
-    next_seen = bc.h_cnt[2];
-    if (bc.h_cnt[3] >= njobs) break;
-    if (drained_before && Kact > 1) {
+  };
+  bool with_fill = false; // the poll in flight carries the slots' control blocks (the queue was drained when it was queued)
+  auto queue_poll = [&](bool fill) {
+    HIPCHECK(hipMemcpyAsync(bc.h_cnt + 4, bc.d_cnt, sizeof(int) * 4, hipMemcpyDeviceToHost, bc.stream));
+    with_fill = fill && Kact > 1;
+    if (with_fill) HIPCHECK(hipMemcpyAsync(bc.h_fill, bc.d_ctl, sizeof(Ctl) * (size_t)Kact, hipMemcpyDeviceToHost, bc.stream));
+    HIPCHECK(hipEventRecord(bc.poll_ev, bc.stream));
+  };
+  static const int first = std::getenv("MVX_BATCH_FIRST") ? std::max(1, std::min(64, std::atoi(std::getenv("MVX_BATCH_FIRST")))) : 8;
+  launch_rounds(predict ? std::max(2, std::min(bc.pred_rounds, 256) - 2) : (njobs <= 2 ? std::min(8, first) : first));
+  queue_poll(false);
+  for (;;) {
+    launch_rounds(later); // runs while the host waits for the poll queued before it
+    HIPCHECK(hipEventSynchronize(bc.poll_ev));
+    if (bc.h_cnt[5] >= njobs) break;
+    const bool drained = bc.h_cnt[4] >= njobs; // no slot can pull a job any more
+    if (with_fill) {
       // Tail of the batch: the queue is empty and the slots finish one by one.  An idle slot of a launch still costs
       // its share of workgroups that start only to leave (512x1024: 132 per slot), so the control blocks that still
-      // hold a job move to the front and the launches shrink.  Their pointers keep addressing their own scratch.
+      // hold a job move to the front and the launches shrink.  Their pointers keep addressing their own scratch.  (The
+      // snapshot is one burst old: a slot idle then is idle for good, one busy then is moved whether it has ended since
+      // or not.)
       int w = 0;
       for (int k = 0; k < Kact; k++) {
         if (bc.h_fill[k].job < 0) continue;
@@ -1716,8 +1796,9 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
       }
       if (w >= 1 && w < Kact) Kact = w;
     }
-    depth = std::min(depth * 2, 32);
+    queue_poll(drained);
   }
+  bc.pred_rounds = std::max(1, bc.h_cnt[7]);
   HIPCHECK(hipMemcpyAsync(bc.h_stage, bc.d_stage, bc.stage_stride * (size_t)njobs, hipMemcpyDeviceToHost, bc.stream));
   HIPCHECK(hipStreamSynchronize(bc.stream));
   for (int j = 0; j < njobs; j++) {
@@ -1725,6 +1806,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     int code = 0, piv = 0;
     int rc = batch_finish_job(bc, j, probs[i], &code, &piv);
     if (code == D_NEED_PHASE1) {
+      g_dbg[4]++;
       fallback.push_back(i);
       probs[i]->piv_since_check += piv; // the single-handle leg below adds its own and applies the refresh rule
     } else {

@@ -157,6 +157,33 @@ __device__ __forceinline__ Cand wave_argbest(const Cand &x, int *who) {
   *who = mk ? (int)__builtin_ctzll(mk) : 0;
   return r;
 }
+// The same where the candidates' indices rise with the lane (one candidate per thread in thread order, or one per wave in
+// wave order): a tie on the first key is settled by the second key's maximum among the tied lanes (MODE 1) and then by
+// the lowest lane, which is the lowest index -- no shuffle reduction unless no lane is valid or a key is not a number.
+// Degenerate node LPs tie on a zero ratio in most dual ratio tests.
+template <int MODE>
+__device__ __forceinline__ Cand wave_argbest_rising(const Cand &x, int *who) {
+  const bool valid = (x.idx != 0);
+  const double key = valid ? (MODE == 0 ? x.k1 : -x.k1) : -INFINITY;
+  const double best = wave_max_f64(key);
+  unsigned long long tied = __ballot(valid && key == best);
+  if (MODE == 1 && __builtin_popcountll(tied) > 1) {
+    const bool mine = valid && key == best;
+    const double best2 = wave_max_f64(mine ? x.k2 : -INFINITY);
+    tied = __ballot(mine && x.k2 == best2);
+  }
+  if (tied != 0) {
+    const int l = (int)__builtin_ctzll(tied);
+    Cand r;
+    r.k1 = rl_d(x.k1, l);
+    r.k2 = rl_d(x.k2, l);
+    r.idx = rl_i(x.idx, l);
+    r.aux = rl_i(x.aux, l);
+    *who = l;
+    return r;
+  }
+  return wave_argbest<MODE>(x, who);
+}
 
 // Kernel constants of one step: pointers, geometry and tolerances copied out of the control block
 // at kernel entry (one burst of scalar loads) instead of being re-fetched, dependently, inside
@@ -718,28 +745,37 @@ struct DcSlot {
   Cand c;
   double pay[4];
 };
+// Workgroup barrier for exchanges that go through LDS only: waits for this wave's LDS traffic, not for its global stores
+// (__syncthreads() carries a release fence that also waits for every outstanding global store to be acknowledged).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Arg-best over the 1024 threads of a block with four doubles of the winner's, in every thread.  slots: 17 entries.
+// The sixteen wave winners are settled by wave 0 alone: k_dsel is bound by instruction issue (sixteen waves on four
+// SIMDs, ~16 k cycles a step), and the same second stage run by all sixteen waves costs four times what one wave
+// running it alone does, against one more LDS read per thread here.
 template <int MODE>
 __device__ __forceinline__ Cand block_argbest16(Cand mine, const double (&pin)[4], double (&pout)[4], DcSlot *slots) {
   const int lane = TIDX & 63, wave = TIDX >> 6;
   int ol;
-  const Cand wb = wave_argbest<MODE>(mine, &ol);
-  double pv[4];
+  const Cand wb = wave_argbest_rising<MODE>(mine, &ol); // thread t holds index t + 1
+  if (lane == 0) slots[wave].c = wb;
+  if (lane == ol) {
 #pragma unroll
-  for (int k = 0; k < 4; k++) pv[k] = rl_d(pin[k], ol);
-  if (lane == 0) {
-    slots[wave].c = wb;
-#pragma unroll
-    for (int k = 0; k < 4; k++) slots[wave].pay[k] = pv[k];
+    for (int k = 0; k < 4; k++) slots[wave].pay[k] = pin[k];
   }
-  __syncthreads();
-  Cand rc{0.0, 0.0, 0, 0};
-  if (lane < 16) rc = slots[lane].c;
-  int wl;
-  const Cand win = wave_argbest<MODE>(rc, &wl);
+  lds_barrier();
+  if (wave == 0) {
+    Cand rc{0.0, 0.0, 0, 0};
+    if (lane < 16) rc = slots[lane].c;
+    int wl;
+    const Cand win = wave_argbest_rising<MODE>(rc, &wl); // lane w holds wave w's best
+    if (lane == 0) slots[16].c = win;
+    if (lane < 4) slots[16].pay[lane] = slots[wl].pay[lane];
+  }
+  lds_barrier(); // slot 16 is rewritten only after the next reduction's first barrier: every wave has read it by then
 #pragma unroll
-  for (int k = 0; k < 4; k++) pout[k] = slots[wl].pay[k];
-  __syncthreads(); // the slots are reused by the next reduction
-  return win;
+  for (int k = 0; k < 4; k++) pout[k] = slots[16].pay[k];
+  return slots[16].c;
 }
 
 // ------------------------------------------------------------------ k_dsel: a dual phase that carries on, on chip
@@ -756,15 +792,32 @@ __device__ __forceinline__ Cand block_argbest16(Cand mine, const double (&pin)[4
 // result is theirs bit for bit.  Whenever the first step is not a plain dual pivot (no infeasible row left: the phase
 // changes; no entering column: the LP is infeasible; Bland's rule in force; bound edits waiting; the pivot limit) it
 // touches nothing and k_select decides; otherwise it leaves `dsel` set and k_select returns at once.
+// what the batched rounds do (scripts/roundstats.py): [0] k_dsel not applicable, [1..DCH_MAX] chains of that length,
+// [DCH_MAX+1] applicable but no plain dual pivot; then k_select: [+2] passthrough, [+3] idle slot, [+4] primal phase 2 step,
+// [+5] dual step, [+6] other phase, [+7] solve ended in this call
+__device__ unsigned long long g_round_hist[DCH_MAX + 10];
+// shader-clock cycles of k_dsel by part (thread 0, summed): [0] entry + state loads, [1] leaving row, [2] row p + ratio test,
+// [3] column q, [4] bookkeeping of the step, [5] exit; [6] steps, [7] launches that ran a chain
+__device__ unsigned long long g_dsel_cycles[8];
 constexpr size_t DSEL_LDS = (size_t)2 * DCH_MAX * 1024 * 8; // the chain's history: one slot per thread, step and side
 __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
   extern __shared__ double dc_hist[]; // [2][DCH_MAX][1024]
-  __shared__ DcSlot s_slots[16];
+  __shared__ DcSlot s_slots[17];
   __shared__ double s_hp[DCH_MAX], s_hq[DCH_MAX], s_misc[4];
   __shared__ ChainStep sts[DCH_MAX]; // the chain so far (every thread holds the same values; thread 0 writes them down)
   c += blockIdx.z;
-  if (c->done != D_RUN || c->phase != PH_DUAL || c->n_edits != 0 || c->dchain_max <= 1 || c->budget == 0 || c->pc_itlim) return;
-  if (c->stall >= c->stall_limit || c->m > 1024 || c->n > 1024 || c->T == nullptr) return;
+  if (c->done != D_RUN || c->phase != PH_DUAL || c->n_edits != 0 || c->dchain_max <= 1 || c->budget == 0 || c->pc_itlim ||
+      c->stall >= c->stall_limit || c->m > 1024 || c->n > 1024 || c->T == nullptr) {
+    if (TIDX == 0 && c->done == D_RUN) atomicAdd(&g_round_hist[0], 1ull);
+    return;
+  }
+  unsigned long long tk = __builtin_readcyclecounter();
+#define DS_STAMP(K)                                                \
+  if (TIDX == 0) {                                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter();  \
+    atomicAdd(&g_dsel_cycles[K], now_ - tk);                       \
+    tk = now_;                                                     \
+  }
   const KC k = load_kc(c);
   const int m = k.m, n = k.n, t = TIDX, kmax = c->dchain_max;
   const size_t ld = (size_t)k.ld;
@@ -786,6 +839,7 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
   for (int kk = 0; kk < kmax; kk++) {
     if (kk >= 1 && ((budget >= 0 && budget < kk + 1) || stall >= stall_limit)) break;
     // ---- leaving row (dev_infeas_row on the carried values)
+    if (kk == 0) DS_STAMP(0);
     Cand rb{0.0, 0.0, 0, 0};
     const double tolb = k.tol_bnd;
     if (ract) {
@@ -803,11 +857,12 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
     if (rw.idx == 0) break; // primal feasible: k_select changes phase
     const int p = rw.idx, p_up = rw.aux;
     const double bp = ro[0], plb = ro[1], pub = ro[2], wp = ro[3];
+    DS_STAMP(1);
     // ---- row p as of step kk: its entries of the earlier pivot columns come from the thread that owns the row
     double a = T[(size_t)p * ld + jc];
     if (i == p)
       for (int l = 0; l < kk; l++) s_hp[l] = DC_HC(l);
-    __syncthreads();
+    lds_barrier();
     for (int l = 0; l < kk; l++) a = chain_apply(sts[l], p, jc, a, s_hp[l], DC_HS(l));
     // dual ratio test (dev_dual_ratio on the carried values)
     Cand best{0.0, 0.0, 0, 0};
@@ -834,15 +889,18 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
     if (qw.idx == 0) break; // no entering column: k_select reports it
     const int q = qw.idx;
     const double apq = qo[0], dq = qo[1], lbq = qo[2], ubq = qo[3];
+    DS_STAMP(2);
     // ---- column q as of step kk: its entries of the earlier scaled rows (and its status) come from its owner
     double cq = T[(size_t)ic * ld + q];
     if (j == q) {
       for (int l = 0; l < kk; l++) s_hq[l] = DC_HS(l);
       s_misc[0] = (double)f;
     }
-    __syncthreads();
+    lds_barrier();
     const int fq = (int)s_misc[0];
     for (int l = 0; l < kk; l++) cq = chain_apply(sts[l], ic, q, cq, DC_HC(l), s_hq[l]);
+    if (TIDX == 0) asm volatile("" ::"v"(cq)); // the stamp that follows waits for the column
+    DS_STAMP(3);
     const double bound = p_up ? pub : plb;
     const int lf = dev_leave_flag(plb, pub, p_up);
     const double s0 = xdiv(bp - bound, apq);
@@ -894,9 +952,12 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
       c->ch_s0[kk] = s0;
     }
     nch = kk + 1;
+    DS_STAMP(4);
+    if (TIDX == 0) atomicAdd(&g_dsel_cycles[6], 1ull);
   }
 #undef DC_HC
 #undef DC_HS
+  if (TIDX == 0) atomicAdd(&g_round_hist[nch ? nch : DCH_MAX + 1], 1ull);
   if (nch == 0) return; // not a plain dual pivot: nothing has been touched, k_select decides
   if (ract) k.dw[i] = dw; // the weights as the chain leaves them, where the next step reads them
   if (t == 0) {
@@ -913,6 +974,9 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
     c->xq = xq0;
     c->leave_flag = lf0;
   }
+  DS_STAMP(5);
+  if (TIDX == 0) atomicAdd(&g_dsel_cycles[7], 1ull);
+#undef DS_STAMP
 }
 
 // ---------------------------------------------------------------------------- k_select
@@ -1107,10 +1171,14 @@ __device__ void pack_mirrors(const Ctl *c, unsigned char *stage, int t0, int ste
 __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
   __shared__ Cand lds[17];
   __shared__ int s_job;
+  if (q.jobs && blockIdx.z == 0 && TIDX == 0) q.counters[2]++; // rounds of this batch so far (one writer per launch)
   c += blockIdx.z; // slot of a batched launch (mvx_simplex_batch); 0 for single solves
   if (c->dsel) { // k_dsel has prepared this step (a dual phase carrying on): nothing to select
     __syncthreads();
-    if (TIDX == 0) c->dsel = 0;
+    if (TIDX == 0) {
+      c->dsel = 0;
+      atomicAdd(&g_round_hist[DCH_MAX + 2], 1ull);
+    }
     return;
   }
   if (q.jobs && c->done != D_RUN) {
@@ -1127,14 +1195,18 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
     if (TIDX == 0) {
       if (old >= 0) {
         __threadfence(); // the staging area is complete before the job counts as finished
-        atomicAdd(&q.counters[1], 1);
+        // the round in which the last job ended (give or take one): the host sizes the next batch's first burst by it
+        if (atomicAdd(&q.counters[1], 1) + 1 == q.count) q.counters[3] = q.counters[2];
       }
       s_job = (q.counters[0] < q.count) ? atomicAdd(&q.counters[0], 1) : q.count;
     }
     __syncthreads();
     const int j = s_job;
     if (j >= q.count) {
-      if (TIDX == 0) c->job = -1;
+      if (TIDX == 0) {
+        c->job = -1;
+        atomicAdd(&g_round_hist[DCH_MAX + 3], 1ull);
+      }
       return;
     }
     const unsigned *src = reinterpret_cast<const unsigned *>(&q.jobs[j]);
@@ -1154,7 +1226,23 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
     }
     __syncthreads();
   }
+  const int ph0 = c->phase;
   select_step(c, lds);
+  if (TIDX == 0 && q.jobs) // thread 0 wrote `done` itself: no barrier
+    atomicAdd(&g_round_hist[DCH_MAX + (c->done != D_RUN ? 7 : ph0 == PH_PRIMAL2 ? 4 : (ph0 == PH_DUAL || ph0 == PH_START) ? 5 : 6)], 1ull);
+}
+
+extern "C" void mvx_debug_round_hist(unsigned long long *out, int reset) { // DCH_MAX + 10 counters (g_round_hist)
+  static const unsigned long long zeros[DCH_MAX + 10] = {};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_hist), sizeof(zeros));
+  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_round_hist), zeros, sizeof(zeros));
+}
+extern "C" void mvx_debug_dsel_cycles(unsigned long long *out, int reset) { // 8 counters (g_dsel_cycles)
+  static const unsigned long long zeros[8] = {};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dsel_cycles), sizeof(zeros));
+  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dsel_cycles), zeros, sizeof(zeros));
 }
 
 // ------------------------------------------------------------------------ phase-1 kernels

@@ -182,7 +182,7 @@ struct SlotScratch { // per-slot scratch the pulled control block is pointed at
 struct BatchQueue {
   const Ctl *jobs;
   const SlotScratch *scratch;
-  int *counters; // [0] next job to hand out, [1] jobs finished and exported
+  int *counters; // [0] next job to hand out, [1] jobs finished and exported, [2] rounds (k_select launches) so far, [3] round of the last job's end
   unsigned char *stage;
   size_t stage_stride;
   int count;
