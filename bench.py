@@ -197,7 +197,9 @@ def secondary(api, with_cpu=True):
     # cap = 0.002, a tree that closes after ~15.7k nodes but is only tens of nodes wide).
     A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3, 0.4)
     nodes = 2000
-    bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=64)  # warm-up
+    # warm-up = the run itself once: the frontier of this tree is a thousand 4 MB node tableaux, and the first run of a
+    # process allocates them (slab arenas, batch contexts); the timed run is the steady state a long B&B job is in
+    bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes)
     t0 = time.perf_counter()
     r = bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=nodes)
     el = time.perf_counter() - t0

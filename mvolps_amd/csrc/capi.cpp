@@ -53,10 +53,10 @@ static double nb_value(int flag, double lb, double ub) {
 static void reset_model(mvx_prob *P) {
   P->m = P->n = 0;
   P->dir = MVX_MIN; // GLPK default [GLPK-recalled]
-  P->A.assign(1, RowPtr());
+  P->A.mut().assign(1, RowPtr());
   P->c.assign(1, 0.0);
   P->kind.assign(1, 0);
-  P->cname.clear();
+  P->cname.mut().clear();
   P->rtype.assign(1, 0); P->rlb.assign(1, 0.0); P->rub.assign(1, 0.0);
   P->ctype.assign(1, 0); P->clb.assign(1, 0.0); P->cub.assign(1, 0.0);
   P->valid = false;
@@ -114,7 +114,7 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   dst->m = src->m; dst->n = src->n; dst->dir = src->dir;
   dst->A = src->A;
   dst->c = src->c; dst->kind = src->kind;
-  if (names) dst->cname = src->cname; else dst->cname.clear();
+  if (names) dst->cname = src->cname; else dst->cname = mvx::CowVec<std::string>();
   dst->rtype = src->rtype; dst->rlb = src->rlb; dst->rub = src->rub;
   dst->ctype = src->ctype; dst->clb = src->clb; dst->cub = src->cub;
   dst->status = src->status; dst->it_cnt = src->it_cnt; dst->bland_cnt = src->bland_cnt; dst->pert_cnt = src->pert_cnt; dst->last_ms = 0.0;
@@ -145,7 +145,7 @@ int mvx_add_rows(mvx_prob *P, int nrs) {
   if (nrs < 1) fault("add_rows: invalid count");
   const int first = P->m + 1;
   for (int r = 0; r < nrs; r++) {
-    P->A.push_back(std::make_shared<std::vector<double>>((size_t)P->n + 1, 0.0));
+    P->A.mut().push_back(std::make_shared<std::vector<double>>((size_t)P->n + 1, 0.0));
     P->rtype.push_back(MVX_FR);
     P->rlb.push_back(-INF);
     P->rub.push_back(INF);
@@ -165,11 +165,11 @@ int mvx_add_cols(mvx_prob *P, int ncs) {
   P->ctype.resize((size_t)P->n + 1, MVX_FX); // GLPK default column: fixed at 0 [GLPK-recalled]
   P->clb.resize((size_t)P->n + 1, 0.0);
   P->cub.resize((size_t)P->n + 1, 0.0);
-  if (!P->cname.empty()) P->cname.resize((size_t)P->n + 1);
+  if (!P->cname.empty()) P->cname.mut().resize((size_t)P->n + 1);
   for (int i = 1; i <= P->m; i++) {
     auto row = std::make_shared<std::vector<double>>(*P->A[i]);
     row->resize((size_t)P->n + 1, 0.0);
-    P->A[i] = row;
+    P->A.mut()[i] = row;
   }
   if (P->valid) mvx::engine_invalidate(P);
   P->status = MVX_UNDEF;
@@ -209,7 +209,7 @@ void mvx_set_mat_row(mvx_prob *P, int i, int len, const int *ind, const double *
     if (ind[k] < 1 || ind[k] > P->n) fault("set_mat_row: column index out of range");
     (*row)[ind[k]] = val[k];
   }
-  P->A[i] = row;
+  P->A.mut()[i] = row;
   if (P->valid) {
     if (P->pos[i] <= 0) mvx::engine_invalidate(P); // row of a non-basic auxiliary changed
     else mvx::engine_row_from_model(P, i);
@@ -230,8 +230,8 @@ void mvx_set_col_kind(mvx_prob *P, int j, int kind) {
 
 void mvx_set_col_name(mvx_prob *P, int j, const char *name) {
   if (j < 1 || j > P->n) fault("set_col_name: column out of range");
-  if (P->cname.size() < (size_t)P->n + 1) P->cname.resize((size_t)P->n + 1);
-  P->cname[j] = name ? name : "";
+  if (P->cname.size() < (size_t)P->n + 1) P->cname.mut().resize((size_t)P->n + 1);
+  P->cname.mut()[j] = name ? name : "";
 }
 
 const char *mvx_get_col_name(const mvx_prob *P, int j) {
@@ -252,14 +252,14 @@ int mvx_load_dense(mvx_prob *P, int m, int n, const double *A, const double *b, 
   P->clb.assign((size_t)n + 1, 0.0);
   P->cub.assign((size_t)n + 1, INF);
   P->m = m;
-  P->A.resize((size_t)m + 1);
+  P->A.mut().resize((size_t)m + 1);
   P->rtype.assign((size_t)m + 1, MVX_UP);
   P->rlb.assign((size_t)m + 1, -INF);
   P->rub.assign((size_t)m + 1, 0.0);
   for (int i = 1; i <= m; i++) {
     auto row = std::make_shared<std::vector<double>>((size_t)n + 1, 0.0);
     std::memcpy(row->data() + 1, A + (size_t)(i - 1) * n, (size_t)n * sizeof(double));
-    P->A[i] = row;
+    P->A.mut()[i] = row;
     P->rub[i] = b[i - 1];
   }
   return 0;

@@ -225,16 +225,34 @@ struct GmiArgs {
 // shared immutable matrix row (1-based, n+1 doubles)
 using RowPtr = std::shared_ptr<std::vector<double>>;
 
+// A vector a clone shares with its source until one of them writes: B&B clones copy a handle thousands of times a second
+// and never touch the row list (a cut appends to it: that node's list parts from its siblings' then) or the names.
+// Reads go through operator[] / get(); every write goes through mut(), which parts from the sharers first.
+template <class T>
+class CowVec {
+  std::shared_ptr<std::vector<T>> p_ = std::make_shared<std::vector<T>>();
+
+public:
+  const T &operator[](size_t i) const { return (*p_)[i]; }
+  size_t size() const { return p_->size(); }
+  bool empty() const { return p_->empty(); }
+  const std::vector<T> &get() const { return *p_; }
+  std::vector<T> &mut() {
+    if (p_.use_count() != 1) p_ = std::make_shared<std::vector<T>>(*p_);
+    return *p_;
+  }
+};
+
 } // namespace mvx
 
 struct mvx_prob {
   // ---- model (host) ----
   int m = 0, n = 0;
   int dir = MVX_MIN;
-  std::vector<mvx::RowPtr> A; // A[i], i=1..m; rows shared between clones (copy-on-write)
+  mvx::CowVec<mvx::RowPtr> A; // A[i], i=1..m; the list and its rows are shared between clones (copy-on-write)
   std::vector<double> c;      // c[0..n]
   std::vector<int> kind;      // kind[1..n]
-  std::vector<std::string> cname;
+  mvx::CowVec<std::string> cname;
   std::vector<int> rtype;
   std::vector<double> rlb, rub; // normalised (+-inf when absent)
   std::vector<int> ctype;

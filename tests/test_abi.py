@@ -64,6 +64,21 @@ def test_model_layer_without_engine():
     assert np.array_equal(P.get_mat_row(2)[1], A[1])
     api.erase_prob(Q.h)
     assert Q.m == 0 and Q.n == 0
+    # the row list and the column names are shared between clones too (copy-on-write): writes on either side part them
+    api.set_col_name(P.h, 3, b"x3")
+    R = P.copy()
+    S = P.copy(capi.OFF)
+    assert api.get_col_name(R.h, 3) == b"x3" and api.get_col_name(S.h, 3) is None
+    api.set_col_name(R.h, 3, b"y3")
+    api.set_col_name(P.h, 4, b"x4")
+    assert api.get_col_name(P.h, 3) == b"x3" and api.get_col_name(R.h, 3) == b"y3"
+    assert api.get_col_name(R.h, 4) is None and api.get_col_name(P.h, 4) == b"x4"
+    assert api.add_rows(P.h, 2) == 6 and (P.m, R.m, S.m) == (7, 5, 5)
+    R.set_mat_row(5, np.array([0, 2], dtype=np.int32), np.array([0.0, 9.0]))
+    assert np.array_equal(P.get_mat_row(5)[1], A[4]) and np.array_equal(S.get_mat_row(5)[1], A[4])
+    assert list(R.get_mat_row(5)[0]) == [2] and list(P.get_mat_row(7)[0]) == []
+    del R
+    assert np.array_equal(P.get_mat_row(1)[1], A[0]) and np.array_equal(S.get_mat_row(1)[1], A[0])
 
 
 def test_engine_refuses_without_device():
