@@ -502,6 +502,8 @@ static std::vector<std::unique_ptr<CutContainer>> round_cuts(const mvx_lp_api *a
 // chosen by cut_select / -cf.
 // Returns the number of rows appended; -1 when the bug-compatible path found its pool empty (nothing generated yet).
 // `pre`: the one cut the lazy modes would generate for this node, already made by round_cuts (nullptr: make it here).
+static double g_t_cut_scan = 0, g_t_cut_copy = 0, g_t_cut_add = 0; // MVX_BNB_TIMING: parts of add_node_cuts (window driver's thread only)
+static double cut_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &prm, bool quirks, CutPool &pool, const CutContainer *pre = nullptr) {
   if (prm.cut_strat == 0) return 0;
   const int na = api->get_num_cols(a);
@@ -509,10 +511,14 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
   if (quirks) {
     if (prm.lazy_pool) {
       // only the pool's LAST cut is ever added (cut.cpp:20): generate just that one
+      const double t0 = cut_now();
       for (int j = na; j >= 1; j--) {
         if (api->get_col_kind(a, j) == MVX_IV && api->get_col_stat(a, j) == MVX_BS) {
           // one cut: the host loop (one row read, one back-substitution) is as fast as a device pass with its set-up
+          const double t1 = cut_now();
+          g_t_cut_scan += t1 - t0;
           pool.replaceLast(pre ? *pre : generateCut3(api, a, j));
+          g_t_cut_copy += cut_now() - t1;
           break;
         }
       }
@@ -529,13 +535,18 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
         if (result.oid != -1) pool.addToPool(std::move(result));
       }
     }
-    return pool.addCutConstraint(a) < 0 ? -1 : 1;
+    const double t2 = cut_now();
+    const int rc = pool.addCutConstraint(a) < 0 ? -1 : 1;
+    g_t_cut_add += cut_now() - t2;
+    return rc;
   }
   std::vector<CutContainer> local;
   std::vector<double> eff;
   if (prm.cut_select == 0 && prm.lazy_pool && pre) {
+    const double t1 = cut_now();
     local.push_back(*pre);
     eff.push_back(0.0);
+    g_t_cut_copy += cut_now() - t1;
   } else if (prm.cut_select == 0 && prm.lazy_pool) {
     // only the last cut generated would be appended (cut.cpp:20): find it from the far end instead of
     // generating one cut per basic integer column (each is a tableau row read + an O(m n) back-substitution)
@@ -585,9 +596,11 @@ static int add_node_cuts(const mvx_lp_api *api, void *a, const mvx_bnb_params &p
         if (!used[(size_t)q] && (best < 0 || eff[(size_t)q] > eff[(size_t)best])) best = q; // ties: first generated
     used[(size_t)best] = 1;
     const CutContainer &cc = local[(size_t)best];
+    const double t2 = cut_now();
     const int index = api->add_rows(a, 1);
     api->set_mat_row(a, index, (int)cc.inds.size() - 1, cc.inds.data(), cc.vals.data());
     api->set_row_bnds(a, index, MVX_LO, cc.lb, 0);
+    g_t_cut_add += cut_now() - t2;
   }
   return take;
 }
@@ -1085,6 +1098,10 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
     leafContainer.erase(leafContainer.begin(), leafContainer.begin() + (long)processed);
   }
   while (!flight.empty()) finalize_oldest();
+  if (timing) {
+    std::fprintf(stderr, "add_node_cuts: column scan %.1f ms, cut copy/generation %.1f ms, row append %.1f ms\n", g_t_cut_scan * 1e3, g_t_cut_copy * 1e3, g_t_cut_add * 1e3);
+    g_t_cut_scan = g_t_cut_copy = g_t_cut_add = 0;
+  }
   if (timing)
     std::fprintf(stderr, "bnb window timing: A %.1f ms  B %.1f ms (printInfo %.1f, clone %.1f, cuts %.1f of which the round's device pass %.1f)  waiting for child solves %.1f ms\n", tA * 1e3,
                  tB * 1e3, tB_info * 1e3, tB_clone * 1e3, tB_cuts * 1e3, tB_rcuts * 1e3, tWait * 1e3);

@@ -53,7 +53,7 @@ static double nb_value(int flag, double lb, double ub) {
 static void reset_model(mvx_prob *P) {
   P->m = P->n = 0;
   P->dir = MVX_MIN; // GLPK default [GLPK-recalled]
-  P->A.mut().assign(1, RowPtr());
+  P->A.reset(1);
   P->c.assign(1, 0.0);
   P->kind.assign(1, 0);
   P->cname.mut().clear();
@@ -92,6 +92,31 @@ void mvx_delete_prob(mvx_prob *P) {
   mvx::release_device(P);
   delete P;
 }
+
+namespace {
+// MVX_API_TIMING=1: host time of the row-edit entry points a cut goes through (printed when the library unloads)
+struct ApiTiming {
+  bool on = std::getenv("MVX_API_TIMING") != nullptr;
+  double t[4] = {0, 0, 0, 0};
+  long calls[4] = {0, 0, 0, 0};
+  ~ApiTiming() {
+    static const char *names[4] = {"add_rows", "set_mat_row", "set_row_bnds", "eval_tab_row"};
+    if (on)
+      for (int k = 0; k < 4; k++)
+        if (calls[k]) std::fprintf(stderr, "mvx_%s: %ld calls, %.1f us each\n", names[k], calls[k], 1e6 * t[k] / calls[k]);
+  }
+} g_api_timing;
+struct ApiTimer {
+  int k;
+  double t0;
+  explicit ApiTimer(int kk) : k(kk), t0(g_api_timing.on ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0) {}
+  ~ApiTimer() {
+    if (!g_api_timing.on) return;
+    g_api_timing.t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+    g_api_timing.calls[k]++;
+  }
+};
+} // namespace
 
 namespace {
 // MVX_COPY_TIMING=1: where a clone's host time goes (printed when the library unloads)
@@ -142,10 +167,11 @@ void mvx_set_obj_dir(mvx_prob *P, int dir) {
 }
 
 int mvx_add_rows(mvx_prob *P, int nrs) {
+  ApiTimer timer_(0);
   if (nrs < 1) fault("add_rows: invalid count");
   const int first = P->m + 1;
   for (int r = 0; r < nrs; r++) {
-    P->A.mut().push_back(std::make_shared<std::vector<double>>((size_t)P->n + 1, 0.0));
+    P->A.push_back(std::make_shared<std::vector<double>>((size_t)P->n + 1, 0.0));
     P->rtype.push_back(MVX_FR);
     P->rlb.push_back(-INF);
     P->rub.push_back(INF);
@@ -169,7 +195,7 @@ int mvx_add_cols(mvx_prob *P, int ncs) {
   for (int i = 1; i <= P->m; i++) {
     auto row = std::make_shared<std::vector<double>>(*P->A[i]);
     row->resize((size_t)P->n + 1, 0.0);
-    P->A.mut()[i] = row;
+    P->A.set((size_t)i, row);
   }
   if (P->valid) mvx::engine_invalidate(P);
   P->status = MVX_UNDEF;
@@ -177,6 +203,7 @@ int mvx_add_cols(mvx_prob *P, int ncs) {
 }
 
 void mvx_set_row_bnds(mvx_prob *P, int i, int type, double lb, double ub) {
+  ApiTimer timer_(2);
   if (i < 1 || i > P->m) fault("set_row_bnds: row out of range");
   const double olb = P->rlb[i], oub = P->rub[i];
   P->rtype[i] = type;
@@ -202,6 +229,7 @@ void mvx_set_obj_coef(mvx_prob *P, int j, double coef) {
 }
 
 void mvx_set_mat_row(mvx_prob *P, int i, int len, const int *ind, const double *val) {
+  ApiTimer timer_(1);
   if (i < 1 || i > P->m) fault("set_mat_row: row out of range");
   if (len < 0 || len > P->n) fault("set_mat_row: invalid length");
   auto row = std::make_shared<std::vector<double>>((size_t)P->n + 1, 0.0);
@@ -209,7 +237,7 @@ void mvx_set_mat_row(mvx_prob *P, int i, int len, const int *ind, const double *
     if (ind[k] < 1 || ind[k] > P->n) fault("set_mat_row: column index out of range");
     (*row)[ind[k]] = val[k];
   }
-  P->A.mut()[i] = row;
+  P->A.set((size_t)i, row);
   if (P->valid) {
     if (P->pos[i] <= 0) mvx::engine_invalidate(P); // row of a non-basic auxiliary changed
     else mvx::engine_row_from_model(P, i);
@@ -252,14 +280,14 @@ int mvx_load_dense(mvx_prob *P, int m, int n, const double *A, const double *b, 
   P->clb.assign((size_t)n + 1, 0.0);
   P->cub.assign((size_t)n + 1, INF);
   P->m = m;
-  P->A.mut().resize((size_t)m + 1);
+  P->A.resize((size_t)m + 1);
   P->rtype.assign((size_t)m + 1, MVX_UP);
   P->rlb.assign((size_t)m + 1, -INF);
   P->rub.assign((size_t)m + 1, 0.0);
   for (int i = 1; i <= m; i++) {
     auto row = std::make_shared<std::vector<double>>((size_t)n + 1, 0.0);
     std::memcpy(row->data() + 1, A + (size_t)(i - 1) * n, (size_t)n * sizeof(double));
-    P->A.mut()[i] = row;
+    P->A.set((size_t)i, row);
     P->rub[i] = b[i - 1];
   }
   return 0;
@@ -287,8 +315,18 @@ void mvx_init_smcp(mvx_smcp *parm) {
   parm->tol_piv = g_tol_piv;
 }
 
-int mvx_simplex(mvx_prob *P, const mvx_smcp *parm) { return mvx::engine_simplex(P, parm); }
+// a model that has just been loaded (or a lineage that has collected many cut rows) holds its rows in its own tail:
+// fold them into a shared head before the handle starts being cloned (mvx_internal.hpp: RowList)
+static inline void settle_rows(mvx_prob *P) {
+  if (P->A.tail_size() > 16) P->A.freeze();
+}
+int mvx_simplex(mvx_prob *P, const mvx_smcp *parm) {
+  settle_rows(P);
+  return mvx::engine_simplex(P, parm);
+}
 int mvx_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm, int *rcs) {
+  for (int k = 0; k < count; k++)
+    if (probs && probs[k]) settle_rows(probs[k]);
   return mvx::engine_simplex_batch(probs, count, parm, rcs);
 }
 
@@ -408,6 +446,7 @@ int mvx_get_mat_row(const mvx_prob *P, int i, int *ind, double *val) {
 }
 
 int mvx_eval_tab_row(const mvx_prob *P, int k, int *ind, double *val) {
+  ApiTimer timer_(3);
   if (!P->valid) fault("eval_tab_row: basis does not exist");
   if (k < 1 || k > P->m + P->n) fault("eval_tab_row: variable out of range");
   const int pos = P->pos[k];

@@ -2370,7 +2370,7 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
     b += bytes;
   };
   dst->m = m;
-  dst->A.mut().resize((size_t)m + 1);
+  dst->A.resize((size_t)m + 1);
   dst->rtype.resize((size_t)m + 1);
   dst->rlb.resize((size_t)m + 1);
   dst->rub.resize((size_t)m + 1);
@@ -2392,7 +2392,7 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   for (int i = m_base + 1; i <= m; i++) {
     auto row = std::make_shared<std::vector<double>>((size_t)n + 1, 0.0);
     get(row->data(), 8 * (size_t)(n + 1));
-    dst->A.mut()[(size_t)i] = row;
+    dst->A.set((size_t)i, row);
   }
   dst->status = (int)h.status;
   dst->it_cnt = (int)h.it_cnt;

@@ -243,13 +243,59 @@ public:
   }
 };
 
+// The rows of a model: a frozen head shared by every clone (one reference count) and this handle's own tail.  B&B clones
+// copy a handle thousands of times a second; what a node adds to its parent's model is a cut row or two, which goes to
+// the tail -- a clone costs one count plus the tail, an append touches nothing shared.  (A plain shared list of 513 row
+// pointers cost 513 counts per clone; a copy-on-write list moved the same cost to every node's first cut.)  freeze()
+// folds the tail into a new head; the solve entry calls it when the tail has grown long (a freshly loaded model).
+class RowList {
+  std::shared_ptr<std::vector<RowPtr>> head_ = std::make_shared<std::vector<RowPtr>>();
+  std::vector<RowPtr> tail_;
+
+public:
+  size_t size() const { return head_->size() + tail_.size(); }
+  const RowPtr &operator[](size_t i) const { return i < head_->size() ? (*head_)[i] : tail_[i - head_->size()]; }
+  size_t tail_size() const { return tail_.size(); }
+  void push_back(RowPtr r) { tail_.push_back(std::move(r)); }
+  void set(size_t i, RowPtr r) {
+    if (i >= head_->size()) {
+      tail_[i - head_->size()] = std::move(r);
+      return;
+    }
+    if (head_.use_count() != 1) head_ = std::make_shared<std::vector<RowPtr>>(*head_);
+    (*head_)[i] = std::move(r);
+  }
+  void resize(size_t n) {
+    if (n >= head_->size()) {
+      tail_.resize(n - head_->size());
+      return;
+    }
+    if (head_.use_count() != 1) head_ = std::make_shared<std::vector<RowPtr>>(head_->begin(), head_->begin() + (long)n);
+    else head_->resize(n);
+    tail_.clear();
+  }
+  void reset(size_t n) { // n empty rows
+    head_ = std::make_shared<std::vector<RowPtr>>();
+    tail_.assign(n, RowPtr());
+  }
+  void freeze() {
+    if (tail_.empty()) return;
+    auto h = std::make_shared<std::vector<RowPtr>>();
+    h->reserve(size());
+    h->insert(h->end(), head_->begin(), head_->end());
+    h->insert(h->end(), tail_.begin(), tail_.end());
+    head_ = std::move(h);
+    tail_.clear();
+  }
+};
+
 } // namespace mvx
 
 struct mvx_prob {
   // ---- model (host) ----
   int m = 0, n = 0;
   int dir = MVX_MIN;
-  mvx::CowVec<mvx::RowPtr> A; // A[i], i=1..m; the list and its rows are shared between clones (copy-on-write)
+  mvx::RowList A; // A[i], i=1..m; rows are shared between clones (copy-on-write), and so is the list's frozen head
   std::vector<double> c;      // c[0..n]
   std::vector<int> kind;      // kind[1..n]
   mvx::CowVec<std::string> cname;
