@@ -17,4 +17,8 @@ rm -rf $O/tr2
 MVX_BNB_TIMING=1 python3 $R/scripts/config5time.py 64 2>&1 | grep "bnb window timing\|nodes_per" | tail -2 >> $O/bnb_phase_times.txt
 python3 $R/bench.py > $O/bench_4096x8192.json 2> $O/bench.err
 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_4096x8192_driver_form.json 2>> $O/bench.err
+python3 $R/scripts/roundstats.py config5 > $O/config5_round_stats.txt 2>/dev/null
+python3 $R/scripts/roundstats.py wide > $O/wide_round_stats.txt 2>/dev/null
+python3 $R/scripts/childtime.py 4096 8192 4 > $O/child_solves_4096x8192.jsonl 2>/dev/null
+python3 $R/scripts/bnbrepeat.py 10 2>/dev/null | grep -v "^first" > $O/bnb_determinism_soak.txt
 ls $O

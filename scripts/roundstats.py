@@ -31,5 +31,5 @@ print("k_select: passthrough", h[10], " idle slot", h[11], " primal step", h[12]
 lib.mvx_debug_dsel_cycles(cyc, 0)
 cy = list(cyc)
 steps, launches = max(1, cy[6]), max(1, cy[7])
-print("k_dsel shader-clock cycles (100 MHz counter: x10 ns): entry %.0f per launch; per step: leaving row %.0f, row p + ratio %.0f, column q %.0f, bookkeeping %.0f; exit %.0f per launch; steps %d launches %d"
+print("k_dsel shader-clock cycles (s_memtime on thread 0; ~2.3 cycles per ns, a barrier charges the slowest wave to the part that follows): entry %.0f per launch; per step: leaving row %.0f, row p + ratio %.0f, column q %.0f, bookkeeping %.0f; exit %.0f per launch; steps %d launches %d"
       % (cy[0] / launches, cy[1] / steps, cy[2] / steps, cy[3] / steps, cy[4] / steps, cy[5] / launches, cy[6], cy[7]))
