@@ -1995,6 +1995,13 @@ void engine_copy(mvx_prob *dst, const mvx_prob *src) {
     return;
   }
   Context &c = ctx();
+  {
+    static thread_local bool bound = false; // clones are made from the B&B driver's helper threads too
+    if (!bound) {
+      HIPCHECK(hipSetDevice(c.dev));
+      bound = true;
+    }
+  }
   MAIN_LOCK(c);
   SolveCtx &sc = c.main;
   void *slab = slab_alloc(c, src->slab_bytes);
