@@ -304,3 +304,32 @@ def test_division_fixup_keeps_a_long_run_bit_exact(gpu, orc):
     got = bnb.branch_and_bound(lpgen.load_ilp(gpu, A, b, c, U), **kw)
     same_result(got, ref)
     assert ref["count"] == 641
+
+
+def test_first_bnb_of_a_fresh_process_is_the_same_tree(gpu):
+    """The first B&B of a process creates what later ones reuse (batch contexts, slab arenas, streams): whatever is set
+    up on the way must be ordered with the launches that use it.  A fresh interpreter runs the first 300 nodes of the
+    wide 512x1024 tree as its very first engine work; pivots and digest must be those of this (warm) process.  (Round 3:
+    a null-stream memset of a new batch context's job counters could land inside the first batch and hand LPs out twice
+    -- trees still right after tableau refreshes, 10x the pivots.)"""
+    import subprocess
+    import sys
+
+    from mvolps_amd import treedigest
+
+    code = (
+        "import json, mvolps_amd\n"
+        "from mvolps_amd import bnb, synth, treedigest\n"
+        "api = mvolps_amd.api()\n"
+        "A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3, 0.4)\n"
+        "r = bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=300, window=64)\n"
+        "print(json.dumps({'count': r['count'], 'pivots': r['total_pivots'], 'digest': treedigest.digest(r)}))\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    A, b, c, U = synth.dense_ilp(512, 1024, 12345, 3, 0.4)
+    here = bnb.branch_and_bound(synth.load_ilp(gpu, A, b, c, U), quirks=0, max_nodes=300, window=64)
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got = json.loads(out.stdout.strip().splitlines()[-1])
+        assert got == {"count": here["count"], "pivots": here["total_pivots"], "digest": treedigest.digest(here)}
