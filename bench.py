@@ -283,7 +283,7 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=la
         st = r["dist"]
         return r, {"nodes": r["count"], "nodes_per_s": r["count"] / el, "pivots": r["total_pivots"], "seconds": el, "children": st["children"],
                    "migrated_images": st["migrated"], "migrated_share": st["migrated"] / max(1, st["children"]),
-                   "migrated_bytes_per_node": st["migrated_bytes"] / max(1, r["count"]), "rounds": st["rounds"],
+                   "migrated_bytes_per_node": st["migrated_bytes"] / max(1, r["count"]), "rounds": st["rounds"], "allreduces": st.get("allreduces"),
                    "nodes_per_round": st.get("nodes_per_round")}
 
     note("wide tree, children on their parent's rank")

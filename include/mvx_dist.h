@@ -64,6 +64,7 @@ typedef struct {
 
 typedef struct {
   long long children, migrated, migrated_bytes, rounds;
+  long long allreduces; /* MAX all-reduces made: one per round (children's bounds and their own window step together) */
 } mvx_dist_stats;
 
 void mvx_dist_default_params(mvx_dist_params *p);

@@ -17,6 +17,7 @@
 #include <limits>
 #include <map>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/mvx_dist.h"
@@ -31,6 +32,13 @@ struct Node {
   int oid, owner;
   double upper;
   bool inital;
+  // what the window step (bs.cpp:114-117 + printInfo) will find when this node is popped: status, objective, number of
+  // violated columns, their fractional sum, the pick, and the pivots of the pop-time re-solve.  A child's creator works it
+  // out right after solving the child -- nothing touches a node's problem between its creation and its pop -- and it
+  // travels in the round's ONE all-reduce next to the child's bound, so popping a window needs no collective at all.
+  bool known = false;
+  double cls[6] = {0, 0, 0, 0, 0, 0};
+  int solver = 0; // the rank that solved it (holds its solution if it turns out integral)
 };
 
 struct Branch {
@@ -100,7 +108,12 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
   const int slack = dp.slack >= 0 ? dp.slack : std::max(1, per_rank / 4);
   const int quirks = prm.reference_quirks, var_strat = prm.var_strat, max_nodes = prm.max_nodes, loop_limit = prm.loop_limit;
   const bool cuts = prm.cut_strat != 0;
-  auto allreduce_max = [&](std::vector<double> &v) -> int { return (comm && world > 1) ? comm->allreduce_max(comm->ctx, v.data(), v.size()) : 0; };
+  long long n_allreduce = 0;
+  auto allreduce_max = [&](std::vector<double> &v) -> int {
+    if (!(comm && world > 1)) return 0;
+    n_allreduce++;
+    return comm->allreduce_max(comm->ctx, v.data(), v.size());
+  };
 
   Tree tree;
   std::vector<Ev> events;
@@ -126,7 +139,7 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
   const long long W_full = (long long)world * per_rank;
   long long round_no = 0;
   std::map<long long, std::vector<int>> win_load; // absolute window number -> nodes per rank already placed in it
-  mvx_dist_stats stats{0, 0, 0, 0};
+  mvx_dist_stats stats{0, 0, 0, 0, 0};
   int rc = 0;
   int late_err = 0; // a failure one rank met AFTER an exchange (unpacking an image): it rides in the next round's first
                     // all-reduce (or in one of its own behind the loop), so that every rank stops in the same place
@@ -146,40 +159,50 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
     }
     const int W = (int)std::min<long long>((long long)queue.size(), W_full);
 
-    // ---- A. solve the window (bs.cpp:114-117, printInfo bs.cpp:135|151)
-    std::vector<double> A((size_t)W * 6 + 1, NEG_INF); // last entry: a rank carries a failure from the last round
-    A[(size_t)W * 6] = (double)late_err;
-    if (!late_err) {
-      // bs.cpp:114-116 copies the node's problem into a scratch and solves the copy; the node is discarded after
-      // this round either way, so its own clone is solved in place
-      std::vector<void *> hs;
-      std::vector<int> ws, before;
-      for (int w = 0; w < W; w++) {
-        const Node &nd = queue[(size_t)w];
-        if (nd.owner != rank) continue;
-        void *a = local.at(nd.oid);
-        hs.push_back(a);
-        ws.push_back(w);
-        before.push_back(api->get_it_cnt(a));
-      }
-      solve_many(api, hs);
-      for (size_t k = 0; k < hs.size(); k++) {
-        double out[5];
-        mvx_bnb_classify(api, hs[k], root, quirks, var_strat, out);
-        double *row = &A[(size_t)ws[k] * 6];
-        for (int t = 0; t < 5; t++) row[t] = out[t];
-        row[5] = (double)(api->get_it_cnt(hs[k]) - before[k]);
-        if (out[0] == 1.0) {
-          std::vector<double> x((size_t)n0);
-          for (int j = 1; j <= n0; j++) x[(size_t)j - 1] = api->get_col_prim(hs[k], j);
-          x_keep[queue[(size_t)ws[k]].oid] = std::move(x);
+    // ---- A. the window (bs.cpp:114-117, printInfo bs.cpp:135|151).  Every node but the root was classified by the rank
+    // that created it (section C) and carries the result; only a window that holds a node not yet classified is solved
+    // here and agreed on by an all-reduce -- every rank sees the same queue, so every rank takes the same branch.
+    std::vector<double> A((size_t)W * 6 + 1, NEG_INF);
+    bool all_known = true;
+    for (int w = 0; w < W; w++) all_known = all_known && queue[(size_t)w].known;
+    if (all_known) {
+      for (int w = 0; w < W; w++)
+        for (int t = 0; t < 6; t++) A[(size_t)w * 6 + (size_t)t] = queue[(size_t)w].cls[t];
+    } else {
+      A[(size_t)W * 6] = (double)late_err; // last entry: a rank carries a failure from the last round
+      if (!late_err) {
+        // bs.cpp:114-116 copies the node's problem into a scratch and solves the copy; the node is discarded after
+        // this round either way, so its own clone is solved in place
+        std::vector<void *> hs;
+        std::vector<int> ws, before;
+        for (int w = 0; w < W; w++) {
+          const Node &nd = queue[(size_t)w];
+          if (nd.owner != rank) continue;
+          void *a = local.at(nd.oid);
+          hs.push_back(a);
+          ws.push_back(w);
+          before.push_back(api->get_it_cnt(a));
+        }
+        solve_many(api, hs);
+        for (size_t k = 0; k < hs.size(); k++) {
+          double out[5];
+          mvx_bnb_classify(api, hs[k], root, quirks, var_strat, out);
+          double *row = &A[(size_t)ws[k] * 6];
+          for (int t = 0; t < 5; t++) row[t] = out[t];
+          row[5] = (double)(api->get_it_cnt(hs[k]) - before[k]);
+          if (out[0] == 1.0) {
+            std::vector<double> x((size_t)n0);
+            for (int j = 1; j <= n0; j++) x[(size_t)j - 1] = api->get_col_prim(hs[k], j);
+            x_keep[queue[(size_t)ws[k]].oid] = std::move(x);
+          }
         }
       }
-    }
-    if ((rc = allreduce_max(A)) != 0) break;
-    if (A[(size_t)W * 6] > 0.0) {
-      rc = MVX_EFAIL;
-      break;
+      for (int w = 0; w < W; w++) queue[(size_t)w].solver = queue[(size_t)w].owner;
+      if ((rc = allreduce_max(A)) != 0) break;
+      if (A[(size_t)W * 6] > 0.0) {
+        rc = MVX_EFAIL;
+        break;
+      }
     }
 
     // ---- B. replay the serial decisions in queue order
@@ -212,7 +235,7 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
             best_lower = obj;
             has_inc = 1;
             inc_oid = nd.oid;
-            inc_owner = nd.owner;
+            inc_owner = nd.solver;
           }
           stop_all = true;
           break;
@@ -227,7 +250,7 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
           best_lower = obj;
           has_inc = 1;
           inc_oid = nd.oid;
-          inc_owner = nd.owner;
+          inc_owner = nd.solver;
         }
       } else if (st == -1) {
         tree.prune[(size_t)nd.oid] = FEAS;
@@ -254,14 +277,15 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
 
     // ---- C. owners create and solve the children (bs.cpp:269-288)
     const size_t nb = branch_list.size();
-    std::vector<double> Cv((nb + 1) * 4, NEG_INF); // last row: [0] = a rank met a node without a cut
+    constexpr size_t CW = 16; // per branching: both bounds, pivots, image bytes, then 6 + 6 for the two children's own window step
+    std::vector<double> Cv((nb + 1) * CW, NEG_INF); // last row: [0] = a rank met a node without a cut, [1] = a rank carries a failure
     std::unordered_map<int, void *> fresh;
     {
       std::vector<void *> kids;
       std::vector<size_t> ks;
       std::vector<int> before;
       bool nocut = false;
-      for (size_t k = 0; k < nb && !nocut; k++) {
+      for (size_t k = 0; k < nb && !nocut && !late_err; k++) {
         const Branch &b = branch_list[k];
         if (b.owner != rank) continue;
         void *a = local.at(b.oid);
@@ -278,17 +302,39 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
         ks.push_back(k);
         before.push_back(api->get_it_cnt(S2) + api->get_it_cnt(S3));
       }
-      if (nocut) Cv[nb * 4] = 1.0;
-      else {
+      if (late_err) Cv[nb * CW + 1] = 1.0;
+      if (nocut) Cv[nb * CW] = 1.0;
+      else if (!late_err) {
         // every child of this round is an independent LP (bs.cpp:279,287): solve them together
         solve_many(api, kids);
         for (size_t t = 0; t < ks.size(); t++) {
           void *S2 = kids[2 * t], *S3 = kids[2 * t + 1];
-          double *row = &Cv[ks[t] * 4];
+          double *row = &Cv[ks[t] * CW];
           row[0] = api->get_obj_val(S2);
           row[1] = api->get_obj_val(S3);
           row[2] = (double)(api->get_it_cnt(S2) + api->get_it_cnt(S3) - before[t]);
-          row[3] = (double)img->pack_size(S2, root);
+        }
+        // ... and their own window step right away: the solve bs.cpp:117 repeats when a node is popped (no pivots unless
+        // the first one ended infeasible or unbounded) and printInfo, which is all a later round needs to know of them
+        std::vector<int> before2(kids.size());
+        for (size_t i = 0; i < kids.size(); i++) before2[i] = api->get_it_cnt(kids[i]);
+        solve_many(api, kids);
+        for (size_t t = 0; t < ks.size(); t++) {
+          double *row = &Cv[ks[t] * CW];
+          for (int side = 0; side < 2; side++) {
+            void *S = kids[2 * t + (size_t)side];
+            double out[5];
+            mvx_bnb_classify(api, S, root, quirks, var_strat, out);
+            double *cl = row + 4 + 6 * side;
+            for (int u = 0; u < 5; u++) cl[u] = out[u];
+            cl[5] = (double)(api->get_it_cnt(S) - before2[2 * t + (size_t)side]);
+            if (out[0] == 1.0) {
+              std::vector<double> x((size_t)n0);
+              for (int j = 1; j <= n0; j++) x[(size_t)j - 1] = api->get_col_prim(S, j);
+              x_keep[side == 0 ? branch_list[ks[t]].s2 : branch_list[ks[t]].s3] = std::move(x);
+            }
+          }
+          row[3] = (double)img->pack_size(kids[2 * t], root); // after the window step: what travels is the node as popped
         }
       }
     }
@@ -296,9 +342,9 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
       for (auto &kv : fresh) api->delete_prob(kv.second);
       break;
     }
-    if (Cv[nb * 4] == 1.0) {
+    if (Cv[nb * CW + 1] == 1.0 || Cv[nb * CW] == 1.0) {
       for (auto &kv : fresh) api->delete_prob(kv.second);
-      rc = MVX_EDIST_NOCUT;
+      rc = Cv[nb * CW + 1] == 1.0 ? MVX_EFAIL : MVX_EDIST_NOCUT;
       break;
     }
 
@@ -353,7 +399,7 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
                   // point-to-point transfer is posted -- a rank that walked away alone would leave its peers waiting
     for (size_t k = 0; k < nb; k++) {
       const Branch &b = branch_list[k];
-      const double *row = &Cv[k * 4];
+      const double *row = &Cv[k * CW];
       const double ub[2] = {row[0], row[1]};
       total_pivots += (long long)row[2];
       const size_t nbytes = (size_t)row[3];
@@ -365,7 +411,11 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
         kid_no++;
         stats.children++;
         tree.bound[(size_t)oid] = ub[t];
-        queue.push_back(Node{oid, owner, ub[t], false});
+        Node kid{oid, owner, ub[t], false};
+        kid.known = true;
+        for (int u = 0; u < 6; u++) kid.cls[u] = row[4 + 6 * t + u];
+        kid.solver = b.owner;
+        queue.push_back(kid);
         cand.push_back({b.ev_at, Ev{MVX_EV_CANDIDATE, oid, ub[t], 0.0, 0, 0}});
         if (owner != b.owner) {
           stats.migrated++;
@@ -428,7 +478,13 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
       drop(queue.front().oid);
       queue.pop_front();
     }
-    for (auto it = x_keep.begin(); it != x_keep.end();) it = (it->first != inc_oid) ? x_keep.erase(it) : std::next(it);
+    // solutions kept for integral nodes: the incumbent's, and those of nodes still waiting in the queue (classified at
+    // their creation, they become incumbents -- or not -- when they are popped)
+    if (x_keep.size() > (size_t)(has_inc ? 1 : 0)) {
+      std::unordered_set<int> waiting;
+      for (const Node &nd : queue) waiting.insert(nd.oid);
+      for (auto it = x_keep.begin(); it != x_keep.end();) it = (it->first != inc_oid && !waiting.count(it->first)) ? x_keep.erase(it) : std::next(it);
+    }
   }
 
   if (rc == 0 && world > 1) { // a failure behind the last exchange has had no all-reduce to ride on yet
@@ -480,6 +536,7 @@ extern "C" int mvx_branchAndBound_dist(const mvx_lp_api *api, const mvx_image_ap
   res->x = dup(x);
   res->total_pivots = total_pivots;
   res->hit_limit = hit_limit;
+  stats.allreduces = n_allreduce;
   if (stats_out) *stats_out = stats;
   return 0;
 }

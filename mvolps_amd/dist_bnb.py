@@ -113,10 +113,16 @@ class HipNodeEngine:
 
 
 class _Node:
-    __slots__ = ("oid", "owner", "upper", "inital")
+    # cls: what the window step (bs.cpp:114-117 + printInfo) will find when the node is popped -- (status, objective,
+    # violated columns, their fractional sum, pick, pivots of the pop-time re-solve) -- worked out by the rank that
+    # created the node right after solving it (nothing touches a node's problem between its creation and its pop) and
+    # shipped in the round's ONE all-reduce next to the child's bound: popping a window needs no collective.
+    # solver: the rank that solved it (holds its solution if it turns out integral).
+    __slots__ = ("oid", "owner", "upper", "inital", "cls", "solver")
 
-    def __init__(self, oid, owner, upper, inital=False):
+    def __init__(self, oid, owner, upper, inital=False, cls=None, solver=None):
         self.oid, self.owner, self.upper, self.inital = oid, owner, upper, inital
+        self.cls, self.solver = cls, owner if solver is None else solver
 
 
 def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limit=200000, per_rank=1, group=None,
@@ -165,7 +171,7 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         slack = max(1, per_rank // 4)
     round_no = 0
     win_load = {}  # absolute window number -> nodes per rank already placed in it
-    stats = {"world": world, "per_rank": per_rank, "deal": deal, "slack": slack, "children": 0, "migrated": 0, "migrated_bytes": 0, "rounds": 0}
+    stats = {"world": world, "per_rank": per_rank, "deal": deal, "slack": slack, "children": 0, "migrated": 0, "migrated_bytes": 0, "rounds": 0, "allreduces": 0}
     cut_params = None
     if cut_strat:
         cut_params = dict(var_strat=var_strat, cut_strat=cut_strat, quirks=quirks, lazy_pool=lazy_pool, cut_select=cut_select,
@@ -180,25 +186,31 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         widths.append(W)
         window = [queue[i] for i in range(W)]
 
-        # ---- A. solve the window (bs.cpp:114-117, printInfo bs.cpp:135|151)
-        A = torch.full((W, 6), NEG_INF, dtype=torch.float64)
-        solved = {}
-        mine = []
-        for w, nd in enumerate(window):
-            if nd.owner != rank:
-                continue
-            # bs.cpp:114-116 copies the node's problem into a scratch and solves the copy; the node is
-            # discarded after this round either way, so its own clone is solved in place
-            a = local[nd.oid]
-            mine.append((w, nd, a, a.it_cnt))
-        engine.solve_many([a for (_, _, a, _) in mine])
-        for w, nd, a, before in mine:
-            st, obj, nviol, acc, pick = engine.classify(a, root, quirks, var_strat)
-            A[w] = torch.tensor([float(st), obj, float(nviol), acc, float(pick), float(a.it_cnt - before)], dtype=torch.float64)
-            solved[nd.oid] = a
-            if st == 1:
-                x_keep[nd.oid] = a.col_prim()
-        A = allreduce_max(A.to(cdev))
+        # ---- A. the window (bs.cpp:114-117, printInfo bs.cpp:135|151).  Every node but the root was classified by the
+        # rank that created it (section C) and carries the result; only a window with a node not yet classified is
+        # solved here and agreed on by an all-reduce (every rank sees the same queue: every rank takes the same branch)
+        if all(nd.cls is not None for nd in window):
+            A = [nd.cls for nd in window]
+        else:
+            A = torch.full((W, 6), NEG_INF, dtype=torch.float64)
+            mine = []
+            for w, nd in enumerate(window):
+                if nd.owner != rank:
+                    continue
+                # bs.cpp:114-116 copies the node's problem into a scratch and solves the copy; the node is
+                # discarded after this round either way, so its own clone is solved in place
+                a = local[nd.oid]
+                mine.append((w, nd, a, a.it_cnt))
+            engine.solve_many([a for (_, _, a, _) in mine])
+            for w, nd, a, before in mine:
+                st, obj, nviol, acc, pick = engine.classify(a, root, quirks, var_strat)
+                A[w] = torch.tensor([float(st), obj, float(nviol), acc, float(pick), float(a.it_cnt - before)], dtype=torch.float64)
+                if st == 1:
+                    x_keep[nd.oid] = a.col_prim()
+            for nd in window:
+                nd.solver = nd.owner
+            A = allreduce_max(A.to(cdev))
+            stats["allreduces"] += 1
 
         # ---- B. replay the serial decisions in queue order
         per_node_events = []
@@ -224,7 +236,7 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
                     bound[nd.oid] = obj
                     prune[nd.oid] = INTG
                     if not quirks:
-                        best_lower, has_inc, inc_oid, inc_owner = obj, 1, nd.oid, nd.owner
+                        best_lower, has_inc, inc_oid, inc_owner = obj, 1, nd.oid, nd.solver
                     stop_all = True
                     break
             nd.upper = obj
@@ -233,7 +245,7 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
                 prune[nd.oid] = INTG
                 ev.append((EV_INTEGER, nd.oid, obj, 0.0, 0, 0))
                 if sg * obj > sg * best_lower:
-                    best_lower, has_inc, inc_oid, inc_owner = obj, 1, nd.oid, nd.owner
+                    best_lower, has_inc, inc_oid, inc_owner = obj, 1, nd.oid, nd.solver
             elif st == -1:
                 prune[nd.oid] = FEAS
                 ev.append((EV_INFEASIBLE, nd.oid, 0.0, 0.0, 0, 0))
@@ -255,24 +267,39 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
             count += 1
 
         # ---- C. owners create and solve the children (bs.cpp:269-288)
-        C = torch.full((max(1, len(branch_list)), 4), NEG_INF, dtype=torch.float64)
+        # one row per branching: both bounds, pivots, image bytes, then 6 + 6 for the two children's own window step
+        C = torch.full((max(1, len(branch_list)), 16), NEG_INF, dtype=torch.float64)
         fresh = {}
         made = []
         for k, (nd, s2, s3, pick, ev) in enumerate(branch_list):
             if nd.owner != rank:
                 continue
-            a = solved[nd.oid]
+            a = local[nd.oid]
             if cut_params is not None and engine.node_cuts(a, cut_params) < 0:  # bs.cpp:249-258
                 raise RuntimeError("node %d generated no cut: bs.cpp would re-add a cut pooled by an earlier node "
                                    "(cut.cpp:16-21), which the coordinator does not carry between ranks" % nd.oid)
             S2, S3 = engine.make_children(a, pick, quirks)  # bs.cpp:261-282
             made.append((k, s2, s3, S2, S3, S2.it_cnt, S3.it_cnt))
         # every child of this round is an independent LP (bs.cpp:279,287): solve them together
-        engine.solve_many([p for (_, _, _, S2, S3, _, _) in made for p in (S2, S3)])
-        for k, s2, s3, S2, S3, b2, b3 in made:
-            C[k] = torch.tensor([S2.obj, S3.obj, float((S2.it_cnt - b2) + (S3.it_cnt - b3)), float(engine.pack_size(S2, root))], dtype=torch.float64)
+        kids = [p for (_, _, _, S2, S3, _, _) in made for p in (S2, S3)]
+        engine.solve_many(kids)
+        first = [(S2.obj, S3.obj, float((S2.it_cnt - b2) + (S3.it_cnt - b3))) for (_, _, _, S2, S3, b2, b3) in made]
+        # ... and their own window step right away: the solve bs.cpp:117 repeats when a node is popped (no pivots unless
+        # the first one ended infeasible or unbounded) and printInfo -- all that a later round needs to know of them
+        before2 = [p.it_cnt for p in kids]
+        engine.solve_many(kids)
+        for i, (k, s2, s3, S2, S3, b2, b3) in enumerate(made):
+            row = list(first[i]) + [0.0]
+            for side, (oid, S) in enumerate(((s2, S2), (s3, S3))):
+                st, obj, nviol, acc, pick = engine.classify(S, root, quirks, var_strat)
+                row += [float(st), obj, float(nviol), acc, float(pick), float(S.it_cnt - before2[2 * i + side])]
+                if st == 1:
+                    x_keep[oid] = S.col_prim()
+            row[3] = float(engine.pack_size(S2, root))  # after the window step: what travels is the node as popped
+            C[k] = torch.tensor(row, dtype=torch.float64)
             fresh[s2], fresh[s3] = S2, S3
         C = allreduce_max(C.to(cdev))
+        stats["allreduces"] += 1
 
         # ---- D. publish the children, give each an owner, migrate the ones that change ranks
         sends, recvs = [], []
@@ -311,13 +338,13 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         for k, (nd, s2, s3, pick, ev) in enumerate(branch_list):
             ub2, ub3, piv, nbytes = float(C[k][0]), float(C[k][1]), int(C[k][2]), int(C[k][3])
             total_pivots += piv
-            for oid, ub in ((s2, ub2), (s3, ub3)):
+            for side, (oid, ub) in enumerate(((s2, ub2), (s3, ub3))):
                 owner = child_seq % world if deal == "roundrobin" else kid_owner[kid_no]
                 child_seq += 1
                 kid_no += 1
                 stats["children"] += 1
                 bound[oid] = ub
-                queue.append(_Node(oid, owner, ub))
+                queue.append(_Node(oid, owner, ub, cls=[float(v) for v in C[k][4 + 6 * side:10 + 6 * side]], solver=nd.owner))
                 ev.append((EV_CANDIDATE, oid, ub, 0.0, 0, 0))
                 if owner != nd.owner:
                     stats["migrated"] += 1
@@ -343,10 +370,12 @@ def branch_and_bound(engine, root, var_strat=0, quirks=1, max_nodes=0, loop_limi
         for _ in range(processed):
             nd = queue.popleft()
             local.pop(nd.oid, None)
-        solved.clear()
-        for oid in list(x_keep):
-            if oid != inc_oid:
-                del x_keep[oid]
+        # solutions kept for integral nodes: the incumbent's, and those of nodes still waiting in the queue
+        if len(x_keep) > (1 if has_inc else 0):
+            waiting = {nd.oid for nd in queue}
+            for oid in list(x_keep):
+                if oid != inc_oid and oid not in waiting:
+                    del x_keep[oid]
 
     # incumbent solution (bs.cpp:181-187) from the rank that solved it
     x = torch.zeros(n0, dtype=torch.float64)

@@ -53,7 +53,7 @@ class DistParams(C.Structure):
 
 
 class DistStats(C.Structure):
-    _fields_ = [("children", C.c_longlong), ("migrated", C.c_longlong), ("migrated_bytes", C.c_longlong), ("rounds", C.c_longlong)]
+    _fields_ = [("children", C.c_longlong), ("migrated", C.c_longlong), ("migrated_bytes", C.c_longlong), ("rounds", C.c_longlong), ("allreduces", C.c_longlong)]
 
 
 def _lib():
@@ -261,6 +261,6 @@ def branch_and_bound(root, comm=None, table=None, image=None, per_rank=64, slack
     L.mvx_bnb_free_result(C.byref(res))
     world = comm.size if comm is not None else 1
     out["dist"] = {"world": world, "per_rank": per_rank, "deal": deal, "slack": dp.slack if dp.slack >= 0 else max(1, per_rank // 4),
-                   "children": st.children, "migrated": st.migrated, "migrated_bytes": st.migrated_bytes, "rounds": st.rounds,
+                   "children": st.children, "migrated": st.migrated, "migrated_bytes": st.migrated_bytes, "rounds": st.rounds, "allreduces": st.allreduces,
                    "coordinator": "mvx_branchAndBound_dist"}
     return out

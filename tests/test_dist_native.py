@@ -95,3 +95,9 @@ def test_world2_on_the_config5_instance(orc, tmp_path):
     assert_same(res[0], res[1])
     assert treedigest.digest(res[0]) == fx["prefix"]["200"]["sha256"]
     assert res[0]["total_pivots"] == fx["prefix"]["200"]["pivots"]
+    # collectives: the root's window, ONE all-reduce per round (the children's bounds and their own window step travel
+    # together), one more in a round that moves a child (the ranks agree that every image could be packed before any
+    # point-to-point transfer is posted), the closing agreement
+    d = res[0]["dist"]
+    print("config-5 prefix, 2 ranks:", d)
+    assert d["rounds"] + 2 <= d["allreduces"] <= 2 * d["rounds"] + 2
