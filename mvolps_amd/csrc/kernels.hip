@@ -795,6 +795,7 @@ __device__ __forceinline__ Cand block_argbest16(Cand mine, const double (&pin)[4
 // what the batched rounds do (scripts/roundstats.py): [0] k_dsel not applicable, [1..DCH_MAX] chains of that length,
 // [DCH_MAX+1] applicable but no plain dual pivot; then k_select: [+2] passthrough, [+3] idle slot, [+4] primal phase 2 step,
 // [+5] dual step, [+6] other phase, [+7] solve ended in this call
+__device__ int g_stats_on; // mvx_debug_stats(1): the counters below are kept (a stamp costs a clock read and a wait)
 __device__ unsigned long long g_round_hist[DCH_MAX + 10];
 // shader-clock cycles of k_dsel by part (thread 0, summed): [0] entry + state loads, [1] leaving row, [2] row p + ratio test,
 // [3] column q, [4] bookkeeping of the step, [5] exit; [6] steps, [7] launches that ran a chain
@@ -808,12 +809,13 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
   c += blockIdx.z;
   if (c->done != D_RUN || c->phase != PH_DUAL || c->n_edits != 0 || c->dchain_max <= 1 || c->budget == 0 || c->pc_itlim ||
       c->stall >= c->stall_limit || c->m > 1024 || c->n > 1024 || c->T == nullptr) {
-    if (TIDX == 0 && c->done == D_RUN) atomicAdd(&g_round_hist[0], 1ull);
+    if (g_stats_on && TIDX == 0 && c->done == D_RUN) atomicAdd(&g_round_hist[0], 1ull);
     return;
   }
-  unsigned long long tk = __builtin_readcyclecounter();
+  const bool stats = g_stats_on != 0;
+  unsigned long long tk = stats ? __builtin_readcyclecounter() : 0ull;
 #define DS_STAMP(K)                                                \
-  if (TIDX == 0) {                                                 \
+  if (stats && TIDX == 0) {                                        \
     const unsigned long long now_ = __builtin_readcyclecounter();  \
     atomicAdd(&g_dsel_cycles[K], now_ - tk);                       \
     tk = now_;                                                     \
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
     lds_barrier();
     const int fq = (int)s_misc[0];
     for (int l = 0; l < kk; l++) cq = chain_apply(sts[l], ic, q, cq, DC_HC(l), s_hq[l]);
-    if (TIDX == 0) asm volatile("" ::"v"(cq)); // the stamp that follows waits for the column
+    if (stats && TIDX == 0) asm volatile("" ::"v"(cq)); // the stamp that follows waits for the column
     DS_STAMP(3);
     const double bound = p_up ? pub : plb;
     const int lf = dev_leave_flag(plb, pub, p_up);
@@ -953,11 +955,11 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
     }
     nch = kk + 1;
     DS_STAMP(4);
-    if (TIDX == 0) atomicAdd(&g_dsel_cycles[6], 1ull);
+    if (stats && TIDX == 0) atomicAdd(&g_dsel_cycles[6], 1ull);
   }
 #undef DC_HC
 #undef DC_HS
-  if (TIDX == 0) atomicAdd(&g_round_hist[nch ? nch : DCH_MAX + 1], 1ull);
+  if (stats && TIDX == 0) atomicAdd(&g_round_hist[nch ? nch : DCH_MAX + 1], 1ull);
   if (nch == 0) return; // not a plain dual pivot: nothing has been touched, k_select decides
   if (ract) k.dw[i] = dw; // the weights as the chain leaves them, where the next step reads them
   if (t == 0) {
@@ -975,7 +977,7 @@ __global__ __launch_bounds__(1024) void k_dsel(Ctl *c) {
     c->leave_flag = lf0;
   }
   DS_STAMP(5);
-  if (TIDX == 0) atomicAdd(&g_dsel_cycles[7], 1ull);
+  if (stats && TIDX == 0) atomicAdd(&g_dsel_cycles[7], 1ull);
 #undef DS_STAMP
 }
 
@@ -1177,7 +1179,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
     __syncthreads();
     if (TIDX == 0) {
       c->dsel = 0;
-      atomicAdd(&g_round_hist[DCH_MAX + 2], 1ull);
+      if (g_stats_on) atomicAdd(&g_round_hist[DCH_MAX + 2], 1ull);
     }
     return;
   }
@@ -1205,7 +1207,7 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
     if (j >= q.count) {
       if (TIDX == 0) {
         c->job = -1;
-        atomicAdd(&g_round_hist[DCH_MAX + 3], 1ull);
+        if (g_stats_on) atomicAdd(&g_round_hist[DCH_MAX + 3], 1ull);
       }
       return;
     }
@@ -1228,10 +1230,14 @@ __global__ __launch_bounds__(1024) void k_select(Ctl *c, BatchQueue q) {
   }
   const int ph0 = c->phase;
   select_step(c, lds);
-  if (TIDX == 0 && q.jobs) // thread 0 wrote `done` itself: no barrier
+  if (TIDX == 0 && q.jobs && g_stats_on) // thread 0 wrote `done` itself: no barrier
     atomicAdd(&g_round_hist[DCH_MAX + (c->done != D_RUN ? 7 : ph0 == PH_PRIMAL2 ? 4 : (ph0 == PH_DUAL || ph0 == PH_START) ? 5 : 6)], 1ull);
 }
 
+extern "C" void mvx_debug_stats(int on) { // switch the round / cycle counters on or off (off at start)
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats_on), &on, sizeof(int));
+}
 extern "C" void mvx_debug_round_hist(unsigned long long *out, int reset) { // DCH_MAX + 10 counters (g_round_hist)
   static const unsigned long long zeros[DCH_MAX + 10] = {};
   (void)hipDeviceSynchronize();

@@ -17,6 +17,7 @@ else:
 bnb.branch_and_bound(synth.load_ilp(api, A, b, c, U), quirks=0, max_nodes=100, window=64)
 out = (C.c_ulonglong * 18)()
 fn = lib.mvx_debug_round_hist
+lib.mvx_debug_stats(1)
 fn(out, 1)
 cyc = (C.c_ulonglong * 8)()
 lib.mvx_debug_dsel_cycles(cyc, 1)
