@@ -505,6 +505,10 @@ def main():
                 "pivots_timed": pivots,
                 "pivots_per_launch": pivots / k_n,
                 "bytes_per_launch": bytes_per_pivot(m, n),
+                "clock": "HIP events around each launch.  rocprofv3 --kernel-trace reads ~13 us more for the same chained launches "
+                         "(profiles/r03_bench_4096x8192_kernel_stats.csv: k_fbc3<8,2> 117 us): with launches queued back to back every "
+                         "kernel's start stamp there is its predecessor's end stamp (all gaps 0.0 in the trace), so the hand-over between "
+                         "kernels is inside the duration; with an idle queue in front (the rank1 leg) the two clocks agree (76.5 / 78.5 us)",
             }
             # the same kernel with ONE pivot per pass (the rank-1 update the north star prices: MVX_CHAIN=1), timed in
             # this run over >= 50 launches
