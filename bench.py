@@ -309,7 +309,7 @@ def dist_bnb_leg(api, dist, rank, world, dev_index, rehearsal, nodes, publish=la
     res["ranks"] = world
     res["per_rank"] = 64
     res["collective"] = {"backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL over xGMI)", "ranks": world,
-                         "ops_per_round": "2 MAX all-reduces + send/recv of migrated node images"}
+                         "ops_per_round": "1 MAX all-reduce (children's bounds and their own window step together) + send/recv of migrated node images"}
     # The same farm through the C++ entry (mvx_branchAndBound_dist, include/mvx_dist.h) with RCCL called directly from
     # libmvolps_rccl.so (its own communicator; torch.distributed only hands the id round).  What has been measured so
     # far is published first: should this part stall on a node it has not met, the line still carries the rest.
