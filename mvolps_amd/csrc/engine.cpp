@@ -63,7 +63,7 @@ void launch_db(Ctl *, int m, int n, hipStream_t);
 void launch_select(Ctl *, hipStream_t, int slots = 1);
 int launch_dsel(Ctl *, int m, int n, hipStream_t, int slots = 1);
 void launch_select_queue(Ctl *, const BatchQueue &q, hipStream_t, int slots);
-void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1, int chained = 0);
+void launch_update(Ctl *, int m, int n, hipStream_t, int slots = 1, int chained = 0, int busy_slots = 0);
 void launch_p1_head(Ctl *, hipStream_t);
 void launch_p1_select(Ctl *, hipStream_t);
 void launch_p1_fix(Ctl *, int n, hipStream_t);
@@ -1760,11 +1760,15 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   static const bool predict = std::getenv("MVX_BATCH_PRED") && std::atoi(std::getenv("MVX_BATCH_PRED")) != 0;
   static const int later = std::getenv("MVX_BATCH_BURST") ? std::max(1, std::min(64, std::atoi(std::getenv("MVX_BATCH_BURST")))) : 4;
   int Kact = K; // slots launched: all of them while the queue has work, the occupied ones once it is drained
+  // slots that still hold a running solve, as of the last poll (an over-estimate by then): the update's tile depth goes
+  // by the work in the launch, not by its slots -- behind the slowest LPs of a batch a launch is a few tableaux deep
+  int busy = K;
+  static const bool busy_tiles = !(std::getenv("MVX_BUSY_TILES") && std::atoi(std::getenv("MVX_BUSY_TILES")) == 0);
   auto launch_rounds = [&](int rounds) {
     for (int d = 0; d < rounds; d++) {
       launch_dsel(bc.d_ctl, m_max, n_max, bc.stream, Kact); // every slot whose dual phase is carrying on: its chain on chip
       launch_select_queue(bc.d_ctl, q, bc.stream, Kact);
-      launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact, 1);
+      launch_update(bc.d_ctl, m_max, n_max, bc.stream, Kact, 1, busy_tiles ? busy : 0);
     }
   };
   bool with_fill = false; // the poll in flight carries the slots' control blocks (the queue was drained when it was queued)
@@ -1782,6 +1786,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
     HIPCHECK(hipEventSynchronize(bc.poll_ev));
     if (bc.h_cnt[5] >= njobs) break;
     const bool drained = bc.h_cnt[4] >= njobs; // no slot can pull a job any more
+    busy = std::max(1, std::min(Kact, njobs - bc.h_cnt[5]));
     if (with_fill) {
       // Tail of the batch: the queue is empty and the slots finish one by one.  An idle slot of a launch still costs
       // its share of workgroups that start only to leave (512x1024: 132 per slot), so the control blocks that still

@@ -4114,11 +4114,13 @@ void launch_select(Ctl *d_ctl, hipStream_t s, int slots) {
 void launch_select_queue(Ctl *d_ctl, const BatchQueue &q, hipStream_t s, int slots) {
   hipLaunchKernelGGL(k_select, dim3(1, 1, slots), dim3(1024), 0, s, d_ctl, q);
 }
-void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots, int chained) {
+void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots, int chained, int busy_slots) {
   const int pairs = (n + 2) / 2;
   const long tiles = (pairs + 255) / 256;
-  // 16-row tiles once the launch still has >= 2048 workgroups, else 8, else 4 (latency-bound sizes)
-  const int tr = ((long)((m + 16) / 16) * tiles * slots >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * slots >= 2048) ? 8 : 4;
+  // 16-row tiles once the launch still has >= 2048 workgroups with work in them, else 8, else 4 (latency-bound sizes);
+  // busy_slots: the slots of a batched launch that still hold a running solve (0: all of them)
+  const long work = busy_slots > 0 ? std::min(busy_slots, slots) : slots;
+  const int tr = ((long)((m + 16) / 16) * tiles * work >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * work >= 2048) ? 8 : 4;
   dim3 grid((unsigned)tiles, (m + tr) / tr, slots);
   const int nt = (tr == 16) ? pick_nt(m, n) : 0;
   if (nt == 1) hipLaunchKernelGGL((k_update<16, 1>), grid, dim3(256), 0, s, d_ctl, chained);
