@@ -977,17 +977,21 @@ int branchAndBoundWindow(const mvx_lp_api *api, void *prob, const mvx_bnb_params
           if (i != 0) acc += getFract(api->get_col_prim(aw, i));
         // cuts go onto the node's own problem (the serial driver's scratch copy `a`): both children inherit them.
         // The replay runs in queue order, so the persistent pool sees the nodes in bs.cpp's order.
+        // bs.cpp:260-261 pick the variable and read its value behind the cut step; both are taken in front of it here: the
+        // pick looks at the violated list and the root problem only, and appending a row leaves every other row's value
+        // as it is -- but it marks the handle's solution mirrors stale, and reading one value afterwards is a device
+        // export and a host round trip per branching node (~40 us, a tenth of the cut modes' run)
+        const int pick = params.pickVar(vars);
+        const double bound = api->get_col_prim(aw, pick);
         ti = now();
         add_node_cuts(api, aw, prm, quirks, pool, pre.empty() ? nullptr : pre[w].get());
         tB_cuts += now() - ti;
-        const int pick = params.pickVar(vars);
         rec.emit(MVX_EV_BRANCHED, node->oid, node->upperBound, acc, (int)vars.size(), pick);
         Branch br;
         br.slot = w;
         // bs.cpp:269-273 clones the solved node twice.  The node itself is dropped at the end of this
         // round, so the second child takes over its problem object instead of cloning it (same state,
         // one device-to-device tableau copy fewer per branching).
-        const double bound = api->get_col_prim(aw, pick);
         const int t = api->get_col_type(aw, pick);
         const double l = api->get_col_lb(aw, pick), u = api->get_col_ub(aw, pick);
         double tc = now();
