@@ -71,6 +71,7 @@ static void reset_model(mvx_prob *P) {
   P->pending.clear();
   P->dmat.reset();
   P->sol_fresh = false;
+  P->fresh_rows = -1;
   P->beta.clear(); P->dj.clear();
 }
 
@@ -150,7 +151,7 @@ void mvx_copy_prob(mvx_prob *dst, const mvx_prob *src, int names) {
   dst->dmat = src->dmat;
   std::memcpy(dst->last_tol, src->last_tol, sizeof(dst->last_tol));
   dst->bvar = src->bvar; dst->nvar = src->nvar; dst->nflag = src->nflag; dst->pos = src->pos;
-  dst->sol_fresh = src->sol_fresh; dst->beta = src->beta; dst->dj = src->dj;
+  dst->sol_fresh = src->sol_fresh; dst->fresh_rows = src->fresh_rows; dst->beta = src->beta; dst->dj = src->dj;
   const double t1 = g_copy_timing.on ? CopyTiming::now() : 0.0;
   mvx::engine_copy(dst, src);
   if (g_copy_timing.on) {
@@ -342,6 +343,7 @@ int mvx_get_status(const mvx_prob *P) { return P->status; }
 
 double mvx_get_obj_val(const mvx_prob *P) {
   if (!P->valid) return P->c[0];
+  if (!P->sol_fresh && P->fresh_rows >= 0) return P->beta[0]; // only rows behind row 0 have been appended / rewritten since the export
   mvx::refresh_solution(P);
   return P->beta[0];
 }
@@ -352,7 +354,10 @@ double mvx_get_obj_coef(const mvx_prob *P, int j) {
 
 static double var_prim(const mvx_prob *P, int k) {
   if (!P->valid) return 0.0;
-  mvx::refresh_solution(P);
+  // A variable that is basic in a row the edits since the last export have not touched (cut rows are appended behind
+  // it: bs.cpp:249-261 adds a cut and then reads the branching variable's value) is read from the mirror as it stands;
+  // anything else exports the solution first.
+  if (!P->sol_fresh && !(P->fresh_rows >= 0 && P->pos[k] > 0 && P->pos[k] <= P->fresh_rows)) mvx::refresh_solution(P);
   const int pos = P->pos[k];
   if (pos > 0) return P->beta[pos];
   const double lb = (k <= P->m) ? P->rlb[k] : P->clb[k - P->m];
@@ -510,7 +515,7 @@ int mvx_unpack(mvx_prob *dst, const mvx_prob *base, const void *dev_buf) {
   dst->A = base->A; dst->c = base->c; dst->kind = base->kind; dst->cname = base->cname;
   dst->rtype = base->rtype; dst->rlb = base->rlb; dst->rub = base->rub;
   dst->ctype = base->ctype; dst->clb = base->clb; dst->cub = base->cub;
-  dst->valid = false; dst->sol_fresh = false;
+  dst->valid = false; dst->sol_fresh = false; dst->fresh_rows = -1;
   return mvx::engine_unpack(dst, dev_buf);
 }
 void mvx_set_tuning(int tr, int hot, int nt) { mvx::tuning(tr, hot, nt); }

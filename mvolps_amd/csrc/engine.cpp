@@ -788,6 +788,7 @@ static void pull_stage(SolveCtx &sc, mvx_prob *P, bool mirrors) {
   P->nflag.assign(nf, nf + P->n + 1);
   rebuild_pos(P);
   P->sol_fresh = true;
+  P->fresh_rows = -1;
 }
 
 void refresh_solution(const mvx_prob *Pc) {
@@ -884,6 +885,7 @@ static bool build_slack_tableau(mvx_prob *P, const int *sflag = nullptr) { // sf
   P->pending.clear(); // the bounds just uploaded are the model's
   P->valid = true;
   P->sol_fresh = false;
+  P->fresh_rows = -1;
   P->status = MVX_UNDEF;
   return true;
 }
@@ -1234,6 +1236,7 @@ static bool job_finalize(SolveJob &J) {
   P->nflag.assign(nf, nf + P->n + 1);
   rebuild_pos(P);
   P->sol_fresh = true;
+  P->fresh_rows = -1;
   float ms = 0.f;
   HIPCHECK(hipEventElapsedTime(&ms, sc.ev_a, sc.ev_b));
   P->last_ms = ms;
@@ -1390,6 +1393,7 @@ static bool job_prepare(SolveJob &J, mvx_prob *P, const mvx_smcp *parm) {
 static int solve_once(mvx_prob *P, const mvx_smcp *parm, bool aux) {
   SolveJob J;
   if (!job_prepare(J, P, parm)) return J.rc;
+  P->fresh_rows = -1; // the solve rewrites the tableau: whatever ends it exports the mirrors anew, or leaves them stale
   Context &c = ctx();
   HIPCHECK(hipSetDevice(c.dev)); // the current device is per host thread (the B&B driver solves from a worker thread)
   std::unique_lock<std::recursive_mutex> main_lock(c.main_mu);
@@ -1664,6 +1668,7 @@ static int batch_finish_job(BatchCtx &bc, int j, mvx_prob *P, int *done_code, in
   P->nflag.assign(nf, nf + P->n + 1);
   rebuild_pos(P);
   P->sol_fresh = true;
+  P->fresh_rows = -1;
   P->last_ms = 0.0;
   P->hint_dual = false;
   switch (snap.done) {
@@ -1701,6 +1706,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
       continue;
     }
     remember_tolerances(P, parm);
+    P->fresh_rows = -1; // as in solve_once
     pending.push_back(i);
     m_cap = std::max(m_cap, P->m_cap);
     ld = std::max(ld, P->ld);
@@ -1822,6 +1828,7 @@ int engine_simplex_batch(mvx_prob **probs, int count, const mvx_smcp *parm_in, i
   for (int i : fallback) {
     // the batch left this handle untouched apart from zero or more completed pivots
     probs[i]->sol_fresh = false;
+    probs[i]->fresh_rows = -1;
     const int rc = engine_simplex_on(probs[i], &parm, true);
     if (rcs) rcs[i] = rc;
   }
@@ -1870,6 +1877,7 @@ void engine_apply_bounds(mvx_prob *P, int k, int type, double old_lb, double old
     if (xn != xo) launch_shift_nonbasic(P->d_T, P->ld, P->m, jj, xn - xo, sc.stream);
   }
   P->sol_fresh = false;
+  P->fresh_rows = -1;
   P->status = MVX_UNDEF;
 }
 
@@ -1893,6 +1901,8 @@ void engine_add_rows(mvx_prob *P, int first, int nrs) {
   P->bvar.resize((size_t)P->m + 1);
   for (int r = 0; r < nrs; r++) P->bvar[first + r] = first + r;
   rebuild_pos(P);
+  // the new rows sit behind the old ones: what the mirrors hold of those stays current
+  P->fresh_rows = P->sol_fresh ? first - 1 : std::min(P->fresh_rows, first - 1);
   P->sol_fresh = false;
   P->status = MVX_UNDEF;
 }
@@ -1958,6 +1968,7 @@ void engine_row_from_model(mvx_prob *P, int i) {
   base[0] = b0;
   rowcomb_into_row(P, w, base, pos);
   P->hint_dual = true; // appended cut rows (cut.cpp:40) leave the basis dual feasible
+  P->fresh_rows = P->sol_fresh ? pos - 1 : std::min(P->fresh_rows, pos - 1); // only tableau row `pos` has been rewritten
   P->sol_fresh = false;
   P->status = MVX_UNDEF;
 }
@@ -1980,6 +1991,7 @@ void engine_recompute_cost_row(mvx_prob *P) {
   base[0] = z;
   rowcomb_into_row(P, w, base, 0);
   P->sol_fresh = false;
+  P->fresh_rows = -1;
   P->status = MVX_UNDEF;
 }
 
@@ -1987,6 +1999,7 @@ void engine_invalidate(mvx_prob *P) {
   P->pending.clear();
   P->valid = false;
   P->sol_fresh = false;
+  P->fresh_rows = -1;
   P->status = MVX_UNDEF;
 }
 
@@ -2013,6 +2026,7 @@ void engine_copy(mvx_prob *dst, const mvx_prob *src) {
   if (!slab) { // out of memory: the clone keeps the model only (mvx_last_error() reads MVX_ENOMEM)
     dst->valid = false;
     dst->sol_fresh = false;
+    dst->fresh_rows = -1;
     dst->status = MVX_UNDEF;
     return;
   }
@@ -2412,6 +2426,7 @@ int engine_unpack(mvx_prob *dst, const void *dev_buf) {
   dst->piv_since_check = (int)h.reserved;
   std::memcpy(dst->last_tol, h.last_tol, sizeof(dst->last_tol));
   dst->sol_fresh = false;
+  dst->fresh_rows = -1;
   release_device(dst);
   dst->pending.clear();
   dst->valid = false;

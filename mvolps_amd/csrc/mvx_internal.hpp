@@ -328,6 +328,10 @@ struct mvx_prob {
   std::vector<int> pos;               // pos[k], k=1..m+n: +row or -column
   // cached solution vectors (refreshed by export after each solve / modification)
   mutable bool sol_fresh = false;
+  // while !sol_fresh: rows 0..fresh_rows of `beta` (and all of `dj`) are still the tableau's -- the only edits since
+  // the last export appended rows behind them or rewrote a row behind them (a cut: cut.cpp:40) -- so reading the value
+  // of a variable that is basic in one of those rows needs no device export (-1: nothing is known to be current)
+  mutable int fresh_rows = -1;
   mutable std::vector<double> beta; // [m+1], beta[0] = objective
   mutable std::vector<double> dj;   // [n+1]
   // ---- device slab ----

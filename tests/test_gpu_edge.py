@@ -135,3 +135,44 @@ def test_many_bound_edits_on_a_fresh_clone(gpu, orc, n_edits):
     for a_, b_ in ((gq, oq), (gr, orr)):
         assert a_.status == b_.status and a_.it_cnt == b_.it_cnt
         assert np.array_equal(a_.tableau(), b_.tableau())
+
+
+def test_values_read_behind_an_appended_cut_row(gpu, orc):
+    """bs.cpp:249-261 appends a cut and THEN reads the branching variable's value.  Appending (or rewriting) a row behind
+    the others leaves their values as they are, so the engine serves them from the mirrors of the last export instead of
+    exporting again; the new row's own value, a bound edit or the next solve make it export.  Every value read on the way
+    must be the oracle's bit for bit."""
+    A, b, c, U = synth.dense_ilp(16, 32, 5, 3)
+    g = lpgen.load_ilp(gpu, A, b, c, U)
+    o = lpgen.load_ilp(orc, A, b, c, U)
+    for P in (g, o):
+        assert P.simplex() == 0
+    n = 32
+    ind = np.arange(n + 1, dtype=np.int32)
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        before = np.array(g.col_prim())
+        obj_before = g.obj
+        v = np.round(rng.normal(size=n) * 2)
+        lb = float(v @ np.array(o.col_prim())) + 0.25
+        for P in (g, o):
+            r = P.api.add_rows(P.h, 1)
+            P.set_mat_row(r, ind, np.concatenate([[0.0], v]))
+            P.api.set_row_bnds(P.h, r, LO, lb, 0.0)
+        # behind the cut, in front of the solve: the old rows' values, one at a time and all at once
+        for j in (1, 7, n):
+            assert g.api.get_col_prim(g.h, j) == o.api.get_col_prim(o.h, j) == before[j - 1]
+        assert np.array_equal(np.array(g.col_prim()), before) and np.array_equal(np.array(o.col_prim()), before)
+        assert g.obj == o.obj == obj_before
+        # the appended row's own value is not in the mirrors: this one exports
+        assert g.api.get_row_prim(g.h, g.m) == o.api.get_row_prim(o.h, o.m)
+        assert np.array_equal(np.array(g.col_prim()), before)
+        # a clone made behind the cut inherits the same view
+        q = g.copy()
+        assert np.array_equal(np.array(q.col_prim()), before)
+        del q
+        for P in (g, o):
+            P.simplex()
+        assert g.status == o.status and g.it_cnt == o.it_cnt, k
+        assert np.array_equal(np.array(g.col_prim()), np.array(o.col_prim())), k
+        assert np.array_equal(g.tableau(), o.tableau()), k
