@@ -4120,7 +4120,12 @@ void launch_update(Ctl *d_ctl, int m, int n, hipStream_t s, int slots, int chain
   // 16-row tiles once the launch still has >= 2048 workgroups with work in them, else 8, else 4 (latency-bound sizes);
   // busy_slots: the slots of a batched launch that still hold a running solve (0: all of them)
   const long work = busy_slots > 0 ? std::min(busy_slots, slots) : slots;
-  const int tr = ((long)((m + 16) / 16) * tiles * work >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * work >= 2048) ? 8 : 4;
+  int tr = ((long)((m + 16) / 16) * tiles * work >= 2048) ? 16 : ((long)((m + 8) / 8) * tiles * work >= 2048) ? 8 : 4;
+  // batched node LPs: the chained update's 16-row tile is 168 VGPRs / 3 waves per SIMD (the exceptions of the chain's
+  // steps sit in its loop), the 4-row one 56 / 8: 2000 nodes of the wide tree 113 ms with 16-row tiles, 111 with 8, 109
+  // with 4 (MVX_UPD_TR=16 / 8 bring the deeper tiles back)
+  static const int tr_cap = std::getenv("MVX_UPD_TR") ? std::atoi(std::getenv("MVX_UPD_TR")) : 4;
+  if (slots > 1 && chained && tr > tr_cap) tr = tr_cap >= 16 ? 16 : tr_cap >= 8 ? 8 : 4;
   dim3 grid((unsigned)tiles, (m + tr) / tr, slots);
   const int nt = (tr == 16) ? pick_nt(m, n) : 0;
   if (nt == 1) hipLaunchKernelGGL((k_update<16, 1>), grid, dim3(256), 0, s, d_ctl, chained);
