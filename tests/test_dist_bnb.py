@@ -151,6 +151,8 @@ def test_world2_on_the_config5_instance(orc, tmp_path):
     assert_same(res[0], res[1])
     assert treedigest.digest(res[0]) == fx["prefix"]["200"]["sha256"]
     assert res[0]["total_pivots"] == fx["prefix"]["200"]["pivots"]
+    # one MAX all-reduce per round (a child's bound and its own window step travel together) plus the root's window
+    assert res[0]["dist"]["allreduces"] == res[0]["dist"]["rounds"] + 1
 
 
 @pytest.mark.parametrize("world", [4, 8])
